@@ -1,0 +1,113 @@
+"""ctypes binding of libhdp_hip.so (include/hdp_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device can
+be initialised, the first compute call raises.  ``load()`` alone (symbol check)
+works without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhdp_hip.so")
+
+HDP_OK = 0
+ERROR_NAMES = {-1: "HDP_EINVAL", -2: "HDP_ENODEV", -3: "HDP_EHIP", -4: "HDP_ENOMEM",
+               -5: "HDP_EUNSUP", -6: "HDP_EQUANT"}
+
+
+class HdpError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+        self.message = message
+
+
+i64, i32, f64, f32, vp, sz = C.c_int64, C.c_int32, C.c_double, C.c_float, C.c_void_p, C.c_size_t
+P = C.POINTER
+
+# name -> (restype, argtypes); mirrors include/hdp_hip.h one to one
+SIGNATURES = {
+    "hdp_init": (C.c_int, [C.c_int]),
+    "hdp_shutdown": (C.c_int, []),
+    "hdp_device_count": (C.c_int, []),
+    "hdp_last_error": (C.c_char_p, []),
+    "hdp_device_info": (C.c_char_p, []),
+    "hdp_dev_alloc": (vp, [sz]),
+    "hdp_dev_free": (C.c_int, [vp]),
+    "hdp_memcpy_h2d": (C.c_int, [vp, vp, sz]),
+    "hdp_memcpy_d2h": (C.c_int, [vp, vp, sz]),
+    "hdp_dev_memset": (C.c_int, [vp, C.c_int, sz]),
+    "hdp_sync": (C.c_int, [vp]),
+    "hdp_event_create": (vp, []),
+    "hdp_event_record": (C.c_int, [vp, vp]),
+    "hdp_event_elapsed_ms": (C.c_int, [vp, vp, P(f32)]),
+    "hdp_event_destroy": (C.c_int, [vp]),
+    "hdp_threshold_plan_create": (C.c_int, [vp, i64, i64, vp, i64, vp, i64, i64, P(vp)]),
+    "hdp_threshold_plan_destroy": (C.c_int, [vp]),
+    "hdp_thresholds_f32_dev": (C.c_int, [vp, vp, i64, vp, vp]),
+    "hdp_thresholds_f32": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, vp, i64, vp, i64, vp]),
+    "hdp_percentiles_table_f32": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, vp, i64, vp]),
+    "hdp_metrics_plan_create": (C.c_int, [vp, i64, i64, vp, i64, vp, vp, i64, i64, P(vp)]),
+    "hdp_metrics_plan_destroy": (C.c_int, [vp]),
+    "hdp_metrics_year_pitch": (i64, [vp]),
+    "hdp_metrics_f32_dev": (C.c_int, [vp, vp, vp, i64, vp, i64, vp, vp]),
+    "hdp_metrics_f32": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, vp]),
+    "hdp_index_heatwaves": (C.c_int, [vp, i64, i64, i64, i64, i64, vp]),
+    "hdp_season_metrics": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
+    "hdp_indicate_hot_days": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
+    "hdp_generate_series_dev": (C.c_int, [vp, i64, i64, i64, vp, C.c_uint64, f32, f32, vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_initialised_device = None
+
+
+def load():
+    """dlopen the library and bind every declared symbol (no GPU needed)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C hdp_amd/csrc` (hipcc --offload-arch=gfx950). hdp_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc):
+    if rc != HDP_OK:
+        msg = load().hdp_last_error().decode("utf-8", "replace")
+        if rc == -6:
+            raise ValueError(msg)  # numba raises ValueError('Quantiles must be in the range [0, 1]')
+        if rc == -1 and msg.startswith("zero-size array"):
+            raise ValueError(msg)  # what np.max([]) raises inside the reference (metric.py:136)
+        raise HdpError(rc, msg)
+
+
+def ensure_device(device=None):
+    """Initialise the HIP device once per process (LOCAL_RANK selects it under torchrun)."""
+    global _initialised_device
+    lib = load()
+    if device is None:
+        if _initialised_device is not None:
+            return lib
+        device = int(os.environ.get("HDP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if _initialised_device != device:
+        check(lib.hdp_init(int(device)))
+        _initialised_device = device
+    return lib
+
+
+def device_info():
+    return ensure_device().hdp_device_info().decode()

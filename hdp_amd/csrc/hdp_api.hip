@@ -1,0 +1,484 @@
+// extern "C" surface of libhdp_hip.so (see include/hdp_hip.h): lifecycle, device-memory
+// plumbing, plan construction for the metrics pass, and the host-pointer entry points that
+// stage caller buffers through HBM in bounded chunks.
+#include "hdp_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+namespace hdp {
+
+static thread_local std::string g_err;
+static int g_device = -1;
+static hipStream_t g_stream = nullptr;
+static std::string g_info;
+
+int set_error(int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+hipStream_t default_stream() { return g_stream; }
+bool device_ready() { return g_device >= 0; }
+
+static hipStream_t pick(void *stream) { return stream ? static_cast<hipStream_t>(stream) : g_stream; }
+
+// Pack an arbitrarily strided host array into [n_cells][T] contiguous floats.
+static void pack_series(const float *x, int64_t c0, int64_t nc, int64_t T, int64_t sc, int64_t st,
+                        float *dst) {
+  if (st == 1) {
+    for (int64_t c = 0; c < nc; ++c) std::memcpy(dst + c * T, x + (c0 + c) * sc, size_t(T) * 4);
+    return;
+  }
+  // time-major (or general) input: walk time in the outer loop so reads stay sequential
+  if (sc == 1) {
+    constexpr int64_t TB = 256;
+    for (int64_t t0 = 0; t0 < T; t0 += TB) {
+      const int64_t t1 = std::min(T, t0 + TB);
+      for (int64_t c = 0; c < nc; ++c) {
+        float *d = dst + c * T;
+        const float *s = x + (c0 + c);
+        for (int64_t t = t0; t < t1; ++t) d[t] = s[t * st];
+      }
+    }
+    return;
+  }
+  for (int64_t c = 0; c < nc; ++c)
+    for (int64_t t = 0; t < T; ++t) dst[c * T + t] = x[(c0 + c) * sc + t * st];
+}
+
+static int64_t chunk_cells_for(int64_t n_cells, int64_t bytes_per_cell) {
+  const int64_t budget = int64_t(1) << 30;  // ~1 GiB of device staging per chunk
+  int64_t c = std::max<int64_t>(1, budget / std::max<int64_t>(1, bytes_per_cell));
+  return std::min(c, n_cells);
+}
+
+}  // namespace hdp
+
+using namespace hdp;
+
+extern "C" {
+
+int hdp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int hdp_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(HDP_ENODEV, "no HIP device visible (%s); libhdp_hip has no CPU fallback",
+                     e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+  HDP_REQUIRE(device >= 0 && device < n, HDP_EINVAL, "device %d outside [0, %d)", device, n);
+  HDP_HIP_TRY(hipSetDevice(device));
+  if (g_stream == nullptr || g_device != device) {
+    if (g_stream) (void)hipStreamDestroy(g_stream);
+    HDP_HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  }
+  g_device = device;
+  hipDeviceProp_t prop;
+  HDP_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s arch=%s CUs=%d LDS/block=%zu HBM=%.1f GiB", prop.name, prop.gcnArchName,
+           prop.multiProcessorCount, (size_t)prop.sharedMemPerBlock,
+           double(prop.totalGlobalMem) / (1024.0 * 1024.0 * 1024.0));
+  g_info = buf;
+  return HDP_OK;
+}
+
+int hdp_shutdown(void) {
+  if (g_stream) {
+    (void)hipStreamSynchronize(g_stream);
+    (void)hipStreamDestroy(g_stream);
+  }
+  g_stream = nullptr;
+  g_device = -1;
+  return HDP_OK;
+}
+
+const char *hdp_last_error(void) { return g_err.c_str(); }
+const char *hdp_device_info(void) { return g_info.c_str(); }
+
+void *hdp_dev_alloc(size_t bytes) {
+  if (!device_ready()) {
+    set_error(HDP_ENODEV, "hdp_init() has not selected a HIP device");
+    return nullptr;
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    set_error(HDP_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+
+int hdp_dev_free(void *p) {
+  if (p) HDP_HIP_TRY(hipFree(p));
+  return HDP_OK;
+}
+
+int hdp_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return HDP_OK;
+}
+
+int hdp_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  HDP_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return HDP_OK;
+}
+
+int hdp_dev_memset(void *dst, int value, size_t bytes) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_HIP_TRY(hipMemsetAsync(dst, value, bytes, g_stream));
+  return HDP_OK;
+}
+
+int hdp_sync(void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_HIP_TRY(hipStreamSynchronize(pick(stream)));
+  return HDP_OK;
+}
+
+void *hdp_event_create(void) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreate(&ev) != hipSuccess) {
+    set_error(HDP_EHIP, "hipEventCreate failed");
+    return nullptr;
+  }
+  return ev;
+}
+
+int hdp_event_record(void *event, void *stream) {
+  HDP_HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), pick(stream)));
+  return HDP_OK;
+}
+
+int hdp_event_elapsed_ms(void *start, void *stop, float *ms) {
+  HDP_HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+  HDP_HIP_TRY(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return HDP_OK;
+}
+
+int hdp_event_destroy(void *event) {
+  if (event) HDP_HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return HDP_OK;
+}
+
+// ---- thresholds ----------------------------------------------------------------------------------
+
+int hdp_thresholds_f32_dev(const hdp_threshold_plan *plan, const float *x_dev, int64_t n_cells,
+                           double *out_dev, void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(plan && (n_cells == 0 || (x_dev && out_dev)), HDP_EINVAL, "NULL plan or buffer");
+  HDP_REQUIRE(n_cells >= 0, HDP_EINVAL, "negative n_cells");
+  return launch_thresholds(plan, x_dev, n_cells, out_dev, pick(stream));
+}
+
+int hdp_thresholds_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell,
+                       int64_t stride_time, const int64_t *time_index, int64_t n_doy, int64_t S,
+                       const int32_t *cols, int64_t W, const double *q, int64_t P, double *out) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n_cells >= 0, HDP_EINVAL, "negative n_cells");
+  HDP_REQUIRE(n_cells == 0 || (x && out), HDP_EINVAL, "NULL buffer");
+  hdp_threshold_plan *plan = nullptr;
+  int rc = hdp_threshold_plan_create(time_index, n_doy, S, cols, W, q, P, T, &plan);
+  if (rc != HDP_OK) return rc;
+  std::unique_ptr<hdp_threshold_plan> guard(plan);
+  if (n_cells == 0) return HDP_OK;
+  const int64_t chunk = chunk_cells_for(n_cells, T * 4 + n_doy * P * 8);
+  DevBuf dx, dout;
+  HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
+  HDP_HIP_TRY(dout.alloc(size_t(chunk) * n_doy * P * 8));
+  std::vector<float> stage;
+  const bool direct = (stride_time == 1 && stride_cell == T);
+  if (!direct) stage.resize(size_t(chunk) * T);
+  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
+    const int64_t nc = std::min(chunk, n_cells - c0);
+    const float *src = x + c0 * T;
+    if (!direct) {
+      pack_series(x, c0, nc, T, stride_cell, stride_time, stage.data());
+      src = stage.data();
+    }
+    HDP_HIP_TRY(hipMemcpyAsync(dx.p, src, size_t(nc) * T * 4, hipMemcpyHostToDevice, g_stream));
+    rc = launch_thresholds(plan, dx.as<float>(), nc, dout.as<double>(), g_stream);
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipMemcpyAsync(out + c0 * n_doy * P, dout.p, size_t(nc) * n_doy * P * 8,
+                               hipMemcpyDeviceToHost, g_stream));
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  }
+  return HDP_OK;
+}
+
+int hdp_percentiles_table_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell,
+                              int64_t stride_time, const int64_t *win, int64_t n_doy, int64_t B,
+                              const double *q, int64_t P, double *out) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n_cells >= 0 && T > 0 && n_doy > 0 && B > 0 && P > 0, HDP_EINVAL, "bad sizes");
+  HDP_REQUIRE(x && win && q && out, HDP_EINVAL, "NULL buffer");
+  for (int64_t i = 0; i < n_doy * B; ++i)
+    HDP_REQUIRE(win[i] >= -T && win[i] < T, HDP_EINVAL, "window index %lld out of range",
+                (long long)win[i]);
+  std::vector<QuantileParam> qp(P);
+  std::vector<int32_t> klo(P), khi(P);
+  for (int64_t p = 0; p < P; ++p) {
+    int64_t a, b;
+    if (quantile_param(q[p], B, &qp[p], &a, &b) != HDP_OK)
+      return set_error(HDP_EQUANT, "Quantiles must be in the range [0, 1]");
+    klo[p] = (int32_t)a;
+    khi[p] = (int32_t)b;
+  }
+  DevBuf dwin, dqp, dklo, dkhi, dx, dout;
+  HDP_HIP_TRY(dwin.upload(win, size_t(n_doy) * B * 8));
+  HDP_HIP_TRY(dqp.upload(qp.data(), size_t(P) * sizeof(QuantileParam)));
+  HDP_HIP_TRY(dklo.upload(klo.data(), size_t(P) * 4));
+  HDP_HIP_TRY(dkhi.upload(khi.data(), size_t(P) * 4));
+  const int64_t chunk = chunk_cells_for(n_cells, T * 4 + n_doy * P * 8);
+  HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
+  HDP_HIP_TRY(dout.alloc(size_t(chunk) * n_doy * P * 8));
+  std::vector<float> stage(size_t(chunk) * T);
+  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
+    const int64_t nc = std::min(chunk, n_cells - c0);
+    pack_series(x, c0, nc, T, stride_cell, stride_time, stage.data());
+    HDP_HIP_TRY(hipMemcpyAsync(dx.p, stage.data(), size_t(nc) * T * 4, hipMemcpyHostToDevice, g_stream));
+    int rc = launch_table_percentiles(dx.as<float>(), nc, T, dwin.as<int64_t>(), n_doy, B,
+                                      dqp.as<QuantileParam>(), dklo.as<int32_t>(), dkhi.as<int32_t>(), P,
+                                      dout.as<double>(), g_stream);
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipMemcpyAsync(out + c0 * n_doy * P, dout.p, size_t(nc) * n_doy * P * 8,
+                               hipMemcpyDeviceToHost, g_stream));
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  }
+  return HDP_OK;
+}
+
+// ---- metrics ------------------------------------------------------------------------------------------
+
+int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, const int64_t *defs,
+                            int64_t D, const int64_t *north, const int64_t *south, int64_t Y, int64_t P,
+                            hdp_metrics_plan **plan_out) {
+  HDP_REQUIRE(plan_out, HDP_EINVAL, "plan_out is NULL");
+  *plan_out = nullptr;
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(doy_map && defs && (Y == 0 || (north && south)), HDP_EINVAL, "NULL table");
+  HDP_REQUIRE(T > 0 && n_doy > 0 && D > 0 && P > 0 && Y >= 0, HDP_EINVAL, "bad sizes");
+  HDP_REQUIRE(T < (int64_t(1) << 30), HDP_EUNSUP, "T too large");
+  HDP_REQUIRE(n_doy < 65536, HDP_EUNSUP, "n_doy too large");
+  const int64_t Tp = (T + 63) & ~int64_t(63);
+  std::vector<uint16_t> dm(Tp, 0);
+  for (int64_t t = 0; t < T; ++t) {
+    int64_t v = doy_map[t];
+    if (v < 0) v += n_doy;  // NumPy negative indexing into the threshold rows
+    HDP_REQUIRE(v >= 0 && v < n_doy, HDP_EINVAL, "doy_map[%lld]=%lld outside the %lld threshold rows",
+                (long long)t, (long long)doy_map[t], (long long)n_doy);
+    dm[t] = (uint16_t)v;
+  }
+  std::vector<int32_t> dd(D * 3);
+  for (int64_t i = 0; i < D * 3; ++i) {
+    HDP_REQUIRE(defs[i] > -(int64_t(1) << 30) && defs[i] < (int64_t(1) << 30), HDP_EINVAL,
+                "definition value out of range");
+    dd[i] = (int32_t)defs[i];
+  }
+  std::vector<int2> ss(std::max<int64_t>(1, 2 * Y));
+  for (int h = 0; h < 2; ++h) {
+    const int64_t *r = h ? south : north;
+    int64_t prev_end = 0;
+    for (int64_t y = 0; y < Y; ++y) {
+      const int64_t a = r[2 * y], b = r[2 * y + 1];
+      // an empty or negative season slice makes the reference raise inside np.max (metric.py:136)
+      HDP_REQUIRE(a >= 0 && b <= T && a < b, HDP_EINVAL,
+                  "zero-size array to reduction operation maximum which has no identity "
+                  "(season %lld of the %s table is [%lld, %lld))",
+                  (long long)y, h ? "southern" : "northern", (long long)a, (long long)b);
+      HDP_REQUIRE(a >= prev_end, HDP_EUNSUP,
+                  "season ranges must be increasing and disjoint for the fused metrics kernel");
+      HDP_REQUIRE(b - a < 32768, HDP_EUNSUP, "season longer than 32767 days does not fit int16");
+      prev_end = b;
+      ss[h * Y + y] = make_int2((int)a, (int)b);
+    }
+  }
+  auto *pl = new hdp_metrics_plan();
+  pl->T = T; pl->n_doy = n_doy; pl->D = D; pl->Y = Y; pl->P = P;
+  pl->Ypitch = (Y + 3) & ~int64_t(3);
+  hipError_t e = pl->doy_map.upload(dm.data(), dm.size() * 2);
+  if (e == hipSuccess) e = pl->defs.upload(dd.data(), dd.size() * 4);
+  if (e == hipSuccess) e = pl->seasons.upload(ss.data(), ss.size() * sizeof(int2));
+  if (e != hipSuccess) {
+    delete pl;
+    return set_error(HDP_EHIP, "uploading metrics plan tables failed: %s", hipGetErrorString(e));
+  }
+  *plan_out = pl;
+  return HDP_OK;
+}
+
+int hdp_metrics_plan_destroy(hdp_metrics_plan *plan) {
+  delete plan;
+  return HDP_OK;
+}
+
+int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan) { return plan ? plan->Ypitch : 0; }
+
+int hdp_metrics_f32_dev(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
+                        int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells,
+                        int16_t *out_dev, void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(plan, HDP_EINVAL, "NULL plan");
+  HDP_REQUIRE(n_cells >= 0 && n_thr_cells > 0, HDP_EINVAL, "bad cell counts");
+  HDP_REQUIRE(n_cells == 0 || (x_dev && thr_dev && is_south_dev), HDP_EINVAL, "NULL buffer");
+  if (plan->Y == 0 || n_cells == 0) return HDP_OK;
+  HDP_REQUIRE(out_dev, HDP_EINVAL, "NULL output");
+  return launch_metrics(plan, x_dev, thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev, pick(stream));
+}
+
+int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
+                    const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                    const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
+                    const int64_t *south, const uint8_t *is_south, int64_t Y, int16_t *out) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n_cells >= 0 && n_thr_cells > 0, HDP_EINVAL, "bad cell counts");
+  HDP_REQUIRE(n_cells == 0 || (x && thr && is_south && (out || Y == 0)), HDP_EINVAL, "NULL buffer");
+  HDP_REQUIRE(n_cells % n_thr_cells == 0, HDP_EINVAL,
+              "n_cells must be a multiple of the number of threshold cells");
+  hdp_metrics_plan *plan = nullptr;
+  int rc = hdp_metrics_plan_create(doy_map, T, n_doy, defs, D, north, south, Y, P, &plan);
+  if (rc != HDP_OK) return rc;
+  std::unique_ptr<hdp_metrics_plan> guard(plan);
+  if (n_cells == 0 || Y == 0) return HDP_OK;
+  const int64_t Yp = plan->Ypitch;
+  // thresholds stay resident for the whole call; series are processed in chunks
+  DevBuf dthr, dx, dsouth, dout, dref;
+  HDP_HIP_TRY(dthr.upload(thr, size_t(n_thr_cells) * n_doy * P * 8));
+  // chunks are multiples of n_thr_cells when members share thresholds, so (c % n_thr_cells) holds
+  int64_t chunk = chunk_cells_for(n_cells, T * 4 + 4 * P * D * (Yp + Y) * 2);
+  if (n_thr_cells < n_cells) {
+    chunk = std::max<int64_t>(n_thr_cells, chunk / n_thr_cells * n_thr_cells);
+  }
+  HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
+  HDP_HIP_TRY(dsouth.alloc(size_t(chunk)));
+  HDP_HIP_TRY(dout.alloc(size_t(4) * P * D * chunk * Yp * 2));
+  HDP_HIP_TRY(dref.alloc(size_t(4) * P * D * chunk * Y * 2));
+  std::vector<float> stage;
+  const bool direct = (stride_time == 1 && stride_cell == T);
+  if (!direct) stage.resize(size_t(chunk) * T);
+  std::vector<int16_t> host_ref(size_t(4) * P * D * chunk * Y);
+  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
+    const int64_t nc = std::min(chunk, n_cells - c0);
+    const float *src = x + c0 * T;
+    if (!direct) {
+      pack_series(x, c0, nc, T, stride_cell, stride_time, stage.data());
+      src = stage.data();
+    }
+    HDP_HIP_TRY(hipMemcpyAsync(dx.p, src, size_t(nc) * T * 4, hipMemcpyHostToDevice, g_stream));
+    HDP_HIP_TRY(hipMemcpyAsync(dsouth.p, is_south + c0, size_t(nc), hipMemcpyHostToDevice, g_stream));
+    // with shared thresholds c0 is a multiple of n_thr_cells, so the modulo mapping is unchanged
+    const double *thr_base = dthr.as<double>() + (n_thr_cells == n_cells ? c0 * n_doy * P : 0);
+    const int64_t ntc = (n_thr_cells == n_cells) ? nc : n_thr_cells;
+    rc = launch_metrics(plan, dx.as<float>(), thr_base, ntc, dsouth.as<uint8_t>(), nc, dout.as<int16_t>(),
+                        g_stream);
+    if (rc != HDP_OK) return rc;
+    rc = launch_metrics_repack(dout.as<int16_t>(), P, D, nc, Y, Yp, dref.as<int16_t>(), g_stream);
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipMemcpyAsync(host_ref.data(), dref.p, size_t(4) * P * D * nc * Y * 2,
+                               hipMemcpyDeviceToHost, g_stream));
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+    // scatter the chunk [P*D][nc][4][Y] into out [P*D][n_cells][4][Y]
+    for (int64_t pd = 0; pd < P * D; ++pd)
+      std::memcpy(out + (pd * n_cells + c0) * 4 * Y, host_ref.data() + pd * nc * 4 * Y,
+                  size_t(nc) * 4 * Y * 2);
+  }
+  return HDP_OK;
+}
+
+// ---- unit-level mirrors ---------------------------------------------------------------------------------
+
+int hdp_index_heatwaves(const uint8_t *hot, int64_t n_series, int64_t T, int64_t min_duration,
+                        int64_t max_break, int64_t max_subs, int64_t *ids) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n_series >= 0 && T >= 0, HDP_EINVAL, "bad sizes");
+  if (n_series * T == 0) return HDP_OK;
+  HDP_REQUIRE(hot && ids, HDP_EINVAL, "NULL buffer");
+  DevBuf dh, di;
+  HDP_HIP_TRY(dh.upload(hot, size_t(n_series) * T));
+  HDP_HIP_TRY(di.alloc(size_t(n_series) * T * 8));
+  int rc = launch_index_heatwaves(dh.as<uint8_t>(), n_series, T, min_duration, max_break, max_subs,
+                                  di.as<int64_t>(), g_stream);
+  if (rc != HDP_OK) return rc;
+  HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  HDP_HIP_TRY(hipMemcpy(ids, di.p, size_t(n_series) * T * 8, hipMemcpyDeviceToHost));
+  return HDP_OK;
+}
+
+int hdp_season_metrics(const int64_t *ids, int64_t n_series, int64_t T, const int64_t *ranges, int64_t Y,
+                       int64_t *out, double *hwa) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n_series >= 0 && T >= 0 && Y >= 0, HDP_EINVAL, "bad sizes");
+  if (n_series * Y == 0) return HDP_OK;
+  HDP_REQUIRE(ids && ranges && out && hwa, HDP_EINVAL, "NULL buffer");
+  for (int64_t y = 0; y < Y; ++y) {
+    int64_t a = ranges[2 * y], b = ranges[2 * y + 1];
+    HDP_REQUIRE(a >= 0 && b <= T && a < b, HDP_EINVAL,
+                "zero-size array to reduction operation maximum which has no identity");
+  }
+  DevBuf di, dr, dout, dh;
+  HDP_HIP_TRY(di.upload(ids, size_t(n_series) * T * 8));
+  HDP_HIP_TRY(dr.upload(ranges, size_t(Y) * 16));
+  HDP_HIP_TRY(dout.alloc(size_t(n_series) * 4 * Y * 8));
+  HDP_HIP_TRY(dh.alloc(size_t(n_series) * Y * 8));
+  int rc = launch_season_metrics(di.as<int64_t>(), n_series, T, dr.as<int64_t>(), Y, dout.as<int64_t>(),
+                                 dh.as<double>(), g_stream);
+  if (rc != HDP_OK) return rc;
+  HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  HDP_HIP_TRY(hipMemcpy(out, dout.p, size_t(n_series) * 4 * Y * 8, hipMemcpyDeviceToHost));
+  HDP_HIP_TRY(hipMemcpy(hwa, dh.p, size_t(n_series) * Y * 8, hipMemcpyDeviceToHost));
+  return HDP_OK;
+}
+
+int hdp_indicate_hot_days(const float *measure, int64_t n_series, int64_t T, const double *thr,
+                          int64_t n_doy, const int64_t *doy_map, uint8_t *hot) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n_series >= 0 && T >= 0 && n_doy > 0, HDP_EINVAL, "bad sizes");
+  if (n_series * T == 0) return HDP_OK;
+  HDP_REQUIRE(measure && thr && doy_map && hot, HDP_EINVAL, "NULL buffer");
+  std::vector<int64_t> dm(T);
+  for (int64_t t = 0; t < T; ++t) {
+    int64_t v = doy_map[t];
+    if (v < 0) v += n_doy;
+    HDP_REQUIRE(v >= 0 && v < n_doy, HDP_EINVAL, "doy_map[%lld] out of range", (long long)t);
+    dm[t] = v;
+  }
+  DevBuf dx, dt, dd, dh;
+  HDP_HIP_TRY(dx.upload(measure, size_t(n_series) * T * 4));
+  HDP_HIP_TRY(dt.upload(thr, size_t(n_series) * n_doy * 8));
+  HDP_HIP_TRY(dd.upload(dm.data(), size_t(T) * 8));
+  HDP_HIP_TRY(dh.alloc(size_t(n_series) * T));
+  int rc = launch_indicate_hot_days(dx.as<float>(), n_series, T, dt.as<double>(), n_doy, dd.as<int64_t>(),
+                                    dh.as<uint8_t>(), g_stream);
+  if (rc != HDP_OK) return rc;
+  HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  HDP_HIP_TRY(hipMemcpy(hot, dh.p, size_t(n_series) * T, hipMemcpyDeviceToHost));
+  return HDP_OK;
+}
+
+int hdp_generate_series_dev(float *x_dev, int64_t n_cells, int64_t T, int64_t cell_offset,
+                            const float *lat_dev, uint64_t seed, float noise_scale, float trend_per_day,
+                            void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n_cells >= 0 && T >= 0, HDP_EINVAL, "bad sizes");
+  if (n_cells * T == 0) return HDP_OK;
+  HDP_REQUIRE(x_dev && lat_dev, HDP_EINVAL, "NULL buffer");
+  return launch_generate(x_dev, n_cells, T, cell_offset, lat_dev, seed, noise_scale, trend_per_day,
+                         pick(stream));
+}
+
+}  // extern "C"

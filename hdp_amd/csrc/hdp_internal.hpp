@@ -1,0 +1,132 @@
+// Internal declarations shared by the translation units of libhdp_hip.so.
+// gfx950 only: wave64, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hdp_hip.h"
+
+namespace hdp {
+
+constexpr int kWave = 64;
+constexpr size_t kLdsPerCU = 160 * 1024;
+
+// ---- error plumbing ---------------------------------------------------------
+int set_error(int code, const char *fmt, ...);
+hipStream_t default_stream();
+bool device_ready();
+
+#define HDP_HIP_TRY(expr)                                                          \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess)                                                          \
+      return hdp::set_error(HDP_EHIP, "%s failed: %s (%s:%d)", #expr,              \
+                            hipGetErrorString(_e), __FILE__, __LINE__);            \
+  } while (0)
+
+#define HDP_REQUIRE(cond, code, ...)                                               \
+  do {                                                                             \
+    if (!(cond)) return hdp::set_error(code, __VA_ARGS__);                         \
+  } while (0)
+
+// Device buffer with RAII (host-side shim only).
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  hipError_t alloc(size_t n) {
+    release();
+    bytes = n;
+    if (n == 0) return hipSuccess;
+    return hipMalloc(&p, n);
+  }
+  hipError_t upload(const void *src, size_t n) {
+    hipError_t e = alloc(n);
+    if (e != hipSuccess || n == 0) return e;
+    return hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// ---- quantile bookkeeping (numba np.quantile arithmetic, arraymath.py) --------
+enum QMode : int32_t { Q_INTERP = 0, Q_MIN = 1, Q_MAX = 2 };
+
+struct QuantileParam {  // one per requested quantile, device-visible POD
+  int32_t mode;
+  int32_t pad;
+  double w_lo;  // (1 - m)
+  double w_hi;  // m
+};
+
+}  // namespace hdp
+
+// ---- plans (opaque in the C ABI) -------------------------------------------------
+struct hdp_threshold_plan {
+  int64_t n_doy = 0, S = 0, W = 0, P = 0, T = 0;
+  int64_t n = 0;          // samples per window = W * S
+  int32_t S_pad = 0;      // column pitch in LDS (floats): sentinel + S + sentinel, odd
+  int32_t Wp = 0;         // W rounded up to a multiple of 4
+  int32_t epl = 0;        // register elements per lane for the column sort (pow2)
+  int32_t rows_per_block = 0, n_blocks = 0, ncols_max = 0;
+  int32_t RP = 0;         // rows_per_block rounded up to 64
+  int32_t steps_top = 0, steps_bot = 0, nt_top = 0, nt_bot = 0;
+  size_t lds_bytes = 0;
+  // device tables
+  hdp::DevBuf blk_row0, blk_nrows, blk_ncols, blk_list_off, blk_list_len;  // int32 [n_blocks]
+  hdp::DevBuf load_list;   // int2 (t, dest) concatenated over blocks
+  hdp::DevBuf cols_local;  // uint16 [n_doy][W] local column of each window member
+  hdp::DevBuf qparam;      // QuantileParam [P]
+  hdp::DevBuf tgt_top, tgt_bot;  // int2 (rank, slot) sorted by rank
+};
+
+struct hdp_metrics_plan {
+  int64_t T = 0, n_doy = 0, D = 0, Y = 0, P = 0;
+  int64_t Ypitch = 0;
+  hdp::DevBuf doy_map;   // uint16 [T rounded up to 64]
+  hdp::DevBuf defs;      // int32 [D][3]
+  hdp::DevBuf seasons;   // int2 [2][Y]  (north, south)
+};
+
+namespace hdp {
+// kernel launchers (defined in the .hip files)
+int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_t n_cells,
+                      double *out_dev, hipStream_t stream);
+int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
+                   int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells,
+                   int16_t *out_dev, hipStream_t stream);
+int launch_table_percentiles(const float *x_dev, int64_t n_cells, int64_t T, const int64_t *win_dev,
+                             int64_t n_doy, int64_t B, const QuantileParam *qp_dev,
+                             const int32_t *klo_dev, const int32_t *khi_dev, int64_t P,
+                             double *out_dev, hipStream_t stream);
+int launch_index_heatwaves(const uint8_t *hot_dev, int64_t n_series, int64_t T, int64_t min_dur,
+                           int64_t max_break, int64_t max_subs, int64_t *ids_dev, hipStream_t stream);
+int launch_season_metrics(const int64_t *ids_dev, int64_t n_series, int64_t T,
+                          const int64_t *ranges_dev, int64_t Y, int64_t *out_dev, double *hwa_dev,
+                          hipStream_t stream);
+int launch_indicate_hot_days(const float *x_dev, int64_t n_series, int64_t T, const double *thr_dev,
+                             int64_t n_doy, const int64_t *doy_map_dev, uint8_t *hot_dev,
+                             hipStream_t stream);
+int launch_generate(float *x_dev, int64_t n_cells, int64_t T, int64_t cell_offset, const float *lat_dev,
+                    uint64_t seed, float noise_scale, float trend_per_day, hipStream_t stream);
+int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,
+                          int64_t Ypitch, int16_t *ref_layout, hipStream_t stream);
+
+// numba rank arithmetic for one quantile over n samples; returns HDP_EQUANT for q
+// outside [0,1] (or NaN).  k_lo/k_hi are 0-based ASCENDING order-statistic indices.
+int quantile_param(double q, int64_t n, QuantileParam *qp, int64_t *k_lo, int64_t *k_hi);
+}  // namespace hdp

@@ -1,0 +1,460 @@
+// Heatwave detection and seasonal aggregation on gfx950.
+//
+// Replaces the Numba function compute_heatwave_metrics (reference hdp/metric.py:304-341)
+// and the P x D Python loops of apply_ufunc(vectorize=True) around it (metric.py:357-366):
+// for every series, percentile and definition: exceedance series -> heatwave ids ->
+// HWF / HWN / HWD / HWA per season.
+//
+// One wavefront per (series, group of 64 (percentile, definition) pairs):
+//   stage A  the wave reads 64 consecutive days per load (coalesced along time) and, for
+//            each percentile, compares them with that day's threshold (staged in LDS as
+//            f32 rounded toward -inf, which preserves `f32 > f64` exactly); __ballot
+//            turns the 64 comparisons into one 64-bit exceedance word in LDS.  The measure
+//            is read from HBM exactly once for all P x D combinations.
+//   stage B  lane l owns pair (p, d) and walks its percentile's words run by run
+//            (ctz on the word / its complement), applying the reference's run/gap state
+//            machine (metric.py:39-58) once per hot RUN rather than per day, and
+//            attributing labelled runs to seasons on the fly.  No id series is stored:
+//            ids only matter through "same id as the previous labelled run in this season".
+//   output   int16, four seasons packed per 8-byte store, layout [4][P][D][series][Ypitch].
+//
+// HBM-bound by design (no MFMA): algorithmic bytes per series =
+//   4*T (measure) + 8*n_doy*P (thresholds) + 2*4*Y*P*D (metrics).
+#include "hdp_internal.hpp"
+
+#include <cmath>
+
+namespace hdp {
+
+struct MetDev {
+  const uint16_t *doy_map;  // [T rounded up to 64]
+  const int32_t *defs;      // [D][3]
+  const int2 *seasons;      // [2][Y]
+  int T, n_doy, D, Y, P, Ypitch, n_groups, np_max, n_doy_pad;
+  int seas_bytes, thr_bytes, wave_bytes;  // LDS carve, all multiples of 16
+};
+
+constexpr int kMetWaves = 4;
+constexpr int kChunkWords = 32;  // 2048 days of exceedance bits per (wave, percentile) in LDS
+
+// largest float <= d (so that  x > d  <=>  x > result  for every float x)
+__device__ __forceinline__ float f64_to_f32_down(double d) {
+  float r = (float)d;  // round to nearest
+  if ((double)r > d) {
+    uint32_t b = __float_as_uint(r);
+    if (r > 0.0f) b -= 1;
+    else if (r < 0.0f) b += 1;
+    else b = 0x80000001u;  // d in (-min_subnormal, 0): step below zero
+    r = __uint_as_float(b);
+  }
+  return r;
+}
+
+struct LaneState {
+  int open, s_open, e_prev;
+  int in_hw, subs, id;
+  int si, hwf, hwn, hwd, cur, last_id;
+  unsigned long long acc_f, acc_n, acc_d, acc_a;
+};
+
+__device__ __forceinline__ void finalize_season(LaneState &st, int Y, int16_t *out_f, int16_t *out_n,
+                                                int16_t *out_d, int16_t *out_a) {
+  const unsigned hwa = st.hwn ? (unsigned)st.hwf / (unsigned)st.hwn : 0u;  // trunc(mean) == HWF // HWN
+  const int sh = 16 * (st.si & 3);
+  st.acc_f |= (unsigned long long)(st.hwf & 0xffff) << sh;
+  st.acc_n |= (unsigned long long)(st.hwn & 0xffff) << sh;
+  st.acc_d |= (unsigned long long)(st.hwd & 0xffff) << sh;
+  st.acc_a |= (unsigned long long)(hwa & 0xffff) << sh;
+  if ((st.si & 3) == 3 || st.si == Y - 1) {
+    const int o = st.si & ~3;
+    *reinterpret_cast<unsigned long long *>(out_f + o) = st.acc_f;
+    *reinterpret_cast<unsigned long long *>(out_n + o) = st.acc_n;
+    *reinterpret_cast<unsigned long long *>(out_d + o) = st.acc_d;
+    *reinterpret_cast<unsigned long long *>(out_a + o) = st.acc_a;
+    st.acc_f = st.acc_n = st.acc_d = st.acc_a = 0;
+  }
+  st.hwf = st.hwn = st.hwd = st.cur = 0;
+  st.last_id = 0;
+  st.si += 1;
+}
+
+// one hot run [s, e) has ended: reference state machine (metric.py:44-58) + season sums
+__device__ __forceinline__ void process_run(LaneState &st, int s, int e, int min_dur, int max_subs,
+                                            const int2 *seas, int Y, int16_t *out_f, int16_t *out_n,
+                                            int16_t *out_d, int16_t *out_a) {
+  const int len = e - s;
+  bool label = false;
+  if (!st.in_hw) {
+    if (len >= min_dur) { st.id += 1; st.in_hw = 1; label = true; }
+  } else if (st.subs < max_subs) {
+    st.subs += 1;
+    label = true;
+  } else {
+    if (len >= min_dur) { st.id += 1; label = true; }
+    else st.in_hw = 0;
+    st.subs = 0;
+  }
+  if (!label) return;
+  while (st.si < Y && seas[st.si].y <= s) finalize_season(st, Y, out_f, out_n, out_d, out_a);
+  while (st.si < Y) {
+    const int2 ab = seas[st.si];
+    if (ab.x >= e) break;
+    const int lo = max(s, ab.x), hi = min(e, ab.y);
+    const int days = hi - lo;
+    st.hwf += days;
+    if (st.id != st.last_id) { st.hwn += 1; st.cur = days; st.last_id = st.id; }
+    else st.cur += days;
+    st.hwd = max(st.hwd, st.cur);
+    if (ab.y <= e) finalize_season(st, Y, out_f, out_n, out_d, out_a);
+    else break;
+  }
+}
+
+__global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel(
+    MetDev md, const float *__restrict__ x, const double *__restrict__ thr, int64_t n_thr_cells,
+    const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // LDS: seasons [2][Y] int2 | per wave: thr32 [np_max][n_doy_pad] f32, bits [np_max][chunk] u64
+  int2 *seas_all = reinterpret_cast<int2 *>(smem);
+  unsigned char *wbase = smem + md.seas_bytes + size_t(wave) * md.wave_bytes;
+  float *thr32 = reinterpret_cast<float *>(wbase);
+  unsigned long long *bits = reinterpret_cast<unsigned long long *>(wbase + md.thr_bytes);
+
+  for (int i = tid; i < 2 * md.Y; i += blockDim.x) seas_all[i] = md.seasons[i];
+  __syncthreads();
+
+  const int64_t task = int64_t(blockIdx.x) * kMetWaves + wave;
+  if (task >= n_cells * md.n_groups) return;  // no barriers below
+  const int64_t cell = task / md.n_groups;
+  const int group = int(task % md.n_groups);
+
+  const int PD = md.P * md.D;
+  const int c0 = group * 64;
+  const int combo = c0 + lane;
+  const bool valid = combo < PD;
+  const int p_lo = c0 / md.D;
+  const int p_hi = min(md.P - 1, (min(PD, c0 + 64) - 1) / md.D);
+  const int np = p_hi - p_lo + 1;
+  const int my_p = valid ? combo / md.D : p_lo;
+  const int my_d = valid ? combo % md.D : 0;
+  const int pi = my_p - p_lo;
+
+  // thresholds of this series -> LDS, f32 rounded toward -inf
+  {
+    const double *tc = thr + (cell % n_thr_cells) * int64_t(md.n_doy) * md.P;
+    for (int d0 = 0; d0 < md.n_doy; d0 += 64) {
+      const int doy = d0 + lane;
+      if (doy < md.n_doy)
+        for (int q = 0; q < np; ++q)
+          thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(doy) * md.P + p_lo + q]);
+    }
+  }
+
+  const int2 *seas = seas_all + (is_south[cell] ? md.Y : 0);
+  const int min_dur = md.defs[my_d * 3 + 0];
+  const int max_break = md.defs[my_d * 3 + 1];
+  const int max_subs = md.defs[my_d * 3 + 2];
+  const int64_t row = ((int64_t(my_p) * md.D + my_d) * n_cells + cell) * md.Ypitch;
+  const int64_t plane = int64_t(md.P) * md.D * n_cells * md.Ypitch;
+  int16_t *out_f = out + row;
+  int16_t *out_n = out_f + plane;
+  int16_t *out_d = out_n + plane;
+  int16_t *out_a = out_d + plane;
+
+  LaneState st;
+  st.open = 0; st.s_open = 0; st.e_prev = -(1 << 30);
+  st.in_hw = 0; st.subs = 0; st.id = 0;
+  st.si = 0; st.hwf = st.hwn = st.hwd = st.cur = 0; st.last_id = 0;
+  st.acc_f = st.acc_n = st.acc_d = st.acc_a = 0;
+
+  const float *xc = x + cell * int64_t(md.T);
+  const int n_words = (md.T + 63) >> 6;
+
+  for (int w0 = 0; w0 < n_words; w0 += kChunkWords) {
+    const int nw = min(kChunkWords, n_words - w0);
+    // ---- stage A: exceedance words for this chunk --------------------------------------
+#pragma unroll 4
+    for (int w = 0; w < nw; ++w) {
+      const int t = (w0 + w) * 64 + lane;
+      const bool in = t < md.T;
+      const float xv = in ? xc[t] : 0.0f;
+      const int dv = md.doy_map[t];  // padded to a multiple of 64
+      for (int q = 0; q < np; ++q) {
+        const bool hot = in && (xv > thr32[q * md.n_doy_pad + dv]);
+        const unsigned long long m = __ballot(hot);
+        if (lane == 0) bits[q * kChunkWords + w] = m;
+      }
+    }
+    // same wave wrote and reads `bits`; LDS ops of one wave complete in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- stage B: run extraction + state machine -----------------------------------------
+    if (valid) {
+      for (int w = 0; w < nw; ++w) {
+        const unsigned long long word = bits[pi * kChunkWords + w];
+        const int t0 = (w0 + w) * 64;
+        int pos = 0;
+        while (pos < 64) {
+          if (!st.open) {
+            const unsigned long long rem = word >> pos;
+            if (rem == 0) break;
+            pos += __ffsll((long long)rem) - 1;
+            st.s_open = t0 + pos;
+            st.open = 1;
+            if (st.s_open - st.e_prev > max_break) st.in_hw = 0;  // metric.py:48-49
+          }
+          const unsigned long long remz = (~word) >> pos;
+          if (remz == 0) break;  // run continues into the next word
+          pos += __ffsll((long long)remz) - 1;
+          const int e = t0 + pos;
+          st.open = 0;
+          process_run(st, st.s_open, e, min_dur, max_subs, seas, md.Y, out_f, out_n, out_d, out_a);
+          st.e_prev = e;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (valid) {
+    if (st.open) process_run(st, st.s_open, md.T, min_dur, max_subs, seas, md.Y, out_f, out_n, out_d, out_a);
+    while (st.si < md.Y) finalize_season(st, md.Y, out_f, out_n, out_d, out_a);
+  }
+}
+
+// device layout [4][P][D][n][Ypitch] -> reference block layout [P][D][n][4][Y]
+__global__ void metrics_repack_kernel(const int16_t *__restrict__ src, int64_t PD, int64_t n, int64_t Y,
+                                      int64_t Ypitch, int16_t *__restrict__ dst) {
+  const int64_t total = PD * n * 4 * Y;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total;
+       i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t y = i % Y;
+    const int64_t m = (i / Y) % 4;
+    const int64_t c = (i / (4 * Y)) % n;
+    const int64_t pd = i / (4 * Y * n);
+    dst[i] = src[((m * PD + pd) * n + c) * Ypitch + y];
+  }
+}
+
+// ---- unit-level mirrors of the njit helpers --------------------------------------------------
+
+// metric.py:280-301
+__global__ void indicate_hot_days_kernel(const float *__restrict__ x, int64_t n_series, int64_t T,
+                                         const double *__restrict__ thr, int64_t n_doy,
+                                         const int64_t *__restrict__ doy_map, uint8_t *__restrict__ hot) {
+  const int64_t total = n_series * T;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total;
+       i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t s = i / T, t = i % T;
+    hot[i] = ((double)x[i] > thr[s * n_doy + doy_map[t]]) ? 1 : 0;
+  }
+}
+
+// metric.py:11-60, one lane per series, streaming over hot runs
+__global__ void index_heatwaves_kernel(const uint8_t *__restrict__ hot, int64_t n_series, int64_t T,
+                                       int64_t min_dur, int64_t max_break, int64_t max_subs,
+                                       int64_t *__restrict__ ids) {
+  const int64_t s = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (s >= n_series) return;
+  const uint8_t *h = hot + s * T;
+  int64_t *o = ids + s * T;
+  bool in_hw = false;
+  int64_t subs = 0, cur = 0, e_prev = -(int64_t(1) << 40);
+  int64_t t = 0;
+  while (t < T) {
+    if (!h[t]) { o[t] = 0; ++t; continue; }
+    const int64_t start = t;
+    while (t < T && h[t]) ++t;
+    const int64_t len = t - start;
+    if (start - e_prev > max_break) in_hw = false;
+    bool label = false;
+    if (!in_hw) {
+      if (len >= min_dur) { ++cur; in_hw = true; label = true; }
+    } else if (subs < max_subs) {
+      ++subs; label = true;
+    } else {
+      if (len >= min_dur) { ++cur; label = true; }
+      else in_hw = false;
+      subs = 0;
+    }
+    for (int64_t u = start; u < t; ++u) o[u] = label ? cur : 0;
+    e_prev = t;
+  }
+}
+
+// metric.py:63-172 for arbitrary (possibly overlapping) ranges and arbitrary id values,
+// one lane per (series, season).  O(len^2), unit-test sizes only.
+__global__ void season_metrics_kernel(const int64_t *__restrict__ ids, int64_t n_series, int64_t T,
+                                      const int64_t *__restrict__ ranges, int64_t Y,
+                                      int64_t *__restrict__ out, double *__restrict__ hwa) {
+  const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n_series * Y) return;
+  const int64_t s = i / Y, y = i % Y;
+  const int64_t a = ranges[2 * y], b = ranges[2 * y + 1];
+  const int64_t *v = ids + s * T;
+  int64_t n_unique = 0, n_nonzero_unique = 0, hwf = 0;
+  int64_t vmin = 0;
+  bool have = false;
+  for (int64_t t = a; t < b; ++t) {
+    const int64_t val = v[t];
+    if (val > 0) ++hwf;  // metric.py:101 counts ids > 0
+    bool first = true;
+    for (int64_t u = a; u < t; ++u)
+      if (v[u] == val) { first = false; break; }
+    if (first) {
+      ++n_unique;
+      if (val != 0) ++n_nonzero_unique;
+      if (!have || val < vmin) { vmin = val; have = true; }
+    }
+  }
+  // metric.py:124-136: with two or more unique values the smallest is dropped
+  const bool drop_min = n_unique >= 2;
+  int64_t longest = 0, total = 0, kept = 0;
+  for (int64_t t = a; t < b; ++t) {
+    const int64_t val = v[t];
+    bool first = true;
+    for (int64_t u = a; u < t; ++u)
+      if (v[u] == val) { first = false; break; }
+    if (!first) continue;
+    if (drop_min && val == vmin) continue;
+    ++kept;
+    if (val == 0) continue;  // length stays 0
+    int64_t cnt = 0;
+    for (int64_t u = a; u < b; ++u) cnt += (v[u] == val);
+    total += cnt;
+    if (cnt > longest) longest = cnt;
+  }
+  const double mean = kept ? (double)total / (double)kept : __longlong_as_double(0x7ff8000000000000LL);
+  int64_t *o = out + s * 4 * Y;
+  o[0 * Y + y] = hwf;
+  o[1 * Y + y] = n_nonzero_unique;
+  o[2 * Y + y] = longest;
+  o[3 * Y + y] = (int64_t)mean;
+  hwa[s * Y + y] = mean;
+}
+
+// ---- synthetic series (reference generator formula, hdp/utils.py:61-78,41) -------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ULL;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+
+__global__ void generate_kernel(float *__restrict__ x, int64_t n_cells, int64_t T, int64_t cell_offset,
+                                const float *__restrict__ lat, uint64_t seed, float noise_scale,
+                                float trend_per_day) {
+  const int64_t total = n_cells * T;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total;
+       i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t c = i / T, t = i % T;
+    const float la = lat[c];
+    const float beta = la < 0.0f ? 90.0f : 270.0f;
+    const float phase = (float)((t + (int64_t)beta) % 365) * (6.283185307179586f / 365.0f);
+    const uint64_t h = splitmix64(seed ^ (uint64_t)((c + cell_offset) * T + t));
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+    x[i] = 20.0f + 2.0f * __sinf(phase) - 10.0f * fabsf(la) / 90.0f + u * noise_scale +
+           (float)t * trend_per_day;
+  }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------
+int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
+                   int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells, int16_t *out_dev,
+                   hipStream_t stream) {
+  if (n_cells == 0) return HDP_OK;
+  MetDev md;
+  md.doy_map = plan->doy_map.as<uint16_t>();
+  md.defs = plan->defs.as<int32_t>();
+  md.seasons = plan->seasons.as<int2>();
+  md.T = (int)plan->T;
+  md.n_doy = (int)plan->n_doy;
+  md.D = (int)plan->D;
+  md.Y = (int)plan->Y;
+  md.P = (int)plan->P;
+  md.Ypitch = (int)plan->Ypitch;
+  const int PD = md.P * md.D;
+  md.n_groups = (PD + 63) / 64;
+  md.np_max = std::min(md.P, 63 / md.D + 2);
+  md.n_doy_pad = (md.n_doy + 3) & ~3;
+  const size_t seas_bytes = (size_t(2) * md.Y * sizeof(int2) + 15) & ~size_t(15);
+  const size_t thr_bytes = (size_t(md.np_max) * md.n_doy_pad * 4 + 15) & ~size_t(15);
+  const size_t per_wave = thr_bytes + size_t(md.np_max) * kChunkWords * 8;
+  const size_t lds = seas_bytes + kMetWaves * per_wave;
+  md.seas_bytes = (int)seas_bytes;
+  md.thr_bytes = (int)thr_bytes;
+  md.wave_bytes = (int)per_wave;
+  HDP_REQUIRE(lds <= kLdsPerCU - 1024, HDP_EUNSUP,
+              "metrics kernel needs %zu bytes of LDS (P=%d, n_doy=%d, Y=%d)", lds, md.P, md.n_doy, md.Y);
+  const int64_t tasks = n_cells * md.n_groups;
+  const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
+  HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
+  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(metrics_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, md, x_dev,
+                     thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+static unsigned grid_for(int64_t total, int block) {
+  int64_t g = (total + block - 1) / block;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,
+                          int64_t Ypitch, int16_t *ref_layout, hipStream_t stream) {
+  const int64_t total = P * D * n_cells * 4 * Y;
+  if (total == 0) return HDP_OK;
+  hipLaunchKernelGGL(metrics_repack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, dev_layout,
+                     P * D, n_cells, Y, Ypitch, ref_layout);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+int launch_indicate_hot_days(const float *x_dev, int64_t n_series, int64_t T, const double *thr_dev,
+                             int64_t n_doy, const int64_t *doy_map_dev, uint8_t *hot_dev,
+                             hipStream_t stream) {
+  if (n_series * T == 0) return HDP_OK;
+  hipLaunchKernelGGL(indicate_hot_days_kernel, dim3(grid_for(n_series * T, 256)), dim3(256), 0, stream,
+                     x_dev, n_series, T, thr_dev, n_doy, doy_map_dev, hot_dev);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+int launch_index_heatwaves(const uint8_t *hot_dev, int64_t n_series, int64_t T, int64_t min_dur,
+                           int64_t max_break, int64_t max_subs, int64_t *ids_dev, hipStream_t stream) {
+  if (n_series == 0) return HDP_OK;
+  hipLaunchKernelGGL(index_heatwaves_kernel, dim3((unsigned)((n_series + 63) / 64)), dim3(64), 0, stream,
+                     hot_dev, n_series, T, min_dur, max_break, max_subs, ids_dev);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+int launch_season_metrics(const int64_t *ids_dev, int64_t n_series, int64_t T, const int64_t *ranges_dev,
+                          int64_t Y, int64_t *out_dev, double *hwa_dev, hipStream_t stream) {
+  if (n_series * Y == 0) return HDP_OK;
+  hipLaunchKernelGGL(season_metrics_kernel, dim3((unsigned)((n_series * Y + 63) / 64)), dim3(64), 0, stream,
+                     ids_dev, n_series, T, ranges_dev, Y, out_dev, hwa_dev);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+int launch_generate(float *x_dev, int64_t n_cells, int64_t T, int64_t cell_offset, const float *lat_dev,
+                    uint64_t seed, float noise_scale, float trend_per_day, hipStream_t stream) {
+  if (n_cells * T == 0) return HDP_OK;
+  hipLaunchKernelGGL(generate_kernel, dim3(grid_for(n_cells * T, 256)), dim3(256), 0, stream, x_dev, n_cells,
+                     T, cell_offset, lat_dev, seed, noise_scale, trend_per_day);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+}  // namespace hdp

@@ -1,0 +1,180 @@
+/*
+ * hdp_hip.h -- C ABI of libhdp_hip.so: the MI355X (gfx950) implementation of the
+ * two data-parallel hot loops of the Heatwave Diagnostics Package.
+ *
+ * The reference (AgentOxygen/HDP) is pure Python + Numba and has no FFI layer;
+ * the array-level boundary it exposes is the two Numba kernels
+ *
+ *   compute_percentiles        gufunc '(t),(d,b),(p)->(d,p)'   hdp/threshold.py:52-78
+ *   compute_heatwave_metrics   njit, called through apply_ufunc with core dims
+ *                              (time),(doy),(time),(),(),(),(year,end_points)->(metric,year)
+ *                                                              hdp/metric.py:304-341,360-366
+ *
+ * plus the njit helpers the reference unit-tests directly (metric.py:11,63,85,105,140).
+ * Every entry point below replaces one of those call sites; the Python host code in
+ * hdp_amd/ binds them with ctypes (see INTEGRATION.md for the stub a maintainer of
+ * the reference would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all arrays are caller-allocated.
+ *   - every function returns 0 on success or a negative HDP_E* code; the message is
+ *     available from hdp_last_error() (thread-local).
+ *   - "host" entry points take host pointers and block until the result is in the
+ *     caller's buffer.  "_dev" entry points take device pointers, enqueue on the
+ *     given hipStream_t (passed as void*, NULL = the library's stream) and do not
+ *     synchronise.
+ *   - a series ("cell") is one grid cell's time series; n_cells flattens every
+ *     non-time dimension (lat, lon[, member]).
+ *   - there is no CPU fallback: without a usable HIP device every compute entry
+ *     point fails with HDP_ENODEV.
+ */
+#ifndef HDP_HIP_H
+#define HDP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDP_OK        0
+#define HDP_EINVAL   -1   /* bad argument (shape, range, NULL) */
+#define HDP_ENODEV   -2   /* no HIP device / hdp_init not called */
+#define HDP_EHIP     -3   /* a HIP runtime call failed */
+#define HDP_ENOMEM   -4   /* device or host allocation failed */
+#define HDP_EUNSUP   -5   /* valid request outside what the kernels support */
+#define HDP_EQUANT   -6   /* quantile outside [0,1]: numba raises ValueError here */
+
+/* ---- lifecycle ----------------------------------------------------------- */
+
+/* Select `device` (ordinal among visible HIP devices) for the calling process and
+ * create the library stream.  One process drives one GPU (one rank per GPU). */
+int hdp_init(int device);
+int hdp_shutdown(void);
+int hdp_device_count(void);
+const char *hdp_last_error(void);
+/* "gfx950 ... CUs ... LDS" description of the active device (static storage). */
+const char *hdp_device_info(void);
+
+/* ---- device memory plumbing (so a Python host needs no other GPU library) -- */
+void *hdp_dev_alloc(size_t bytes);
+int hdp_dev_free(void *p);
+int hdp_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int hdp_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int hdp_dev_memset(void *dst_dev, int value, size_t bytes);
+int hdp_sync(void *stream);
+/* hipEvent-based timing on `stream`: returns an opaque handle / elapsed ms. */
+void *hdp_event_create(void);
+int hdp_event_record(void *event, void *stream);
+int hdp_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+int hdp_event_destroy(void *event);
+
+/* ---- thresholds: replaces compute_percentiles (threshold.py:52-78) -------- */
+
+/*
+ * Plan = device-resident tables for one (calendar, window, quantile set):
+ *   time_index [n_doy][S]  int64  time indices of the samples of each day-of-year
+ *                                 row, -1 padded (the table threshold.py:35-39 builds;
+ *                                 -1 samples the LAST time step, as NumPy indexing does)
+ *   cols       [n_doy][W]  int32  for window row d, the W day-of-year rows whose
+ *                                 samples form it (threshold.py:43-48; repeats allowed,
+ *                                 this is where the reflected upper edge lives)
+ *   q          [P]         double quantiles in [0,1]
+ * Expanding time_index[cols[d][w]] over w reproduces row d of the reference's
+ * [n_doy, W*S] gather table exactly.
+ */
+typedef struct hdp_threshold_plan hdp_threshold_plan;
+
+int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_doy, int64_t S,
+                              const int32_t *cols, int64_t W,
+                              const double *q, int64_t P, int64_t T,
+                              hdp_threshold_plan **plan_out);
+int hdp_threshold_plan_destroy(hdp_threshold_plan *plan);
+
+/* x_dev [n_cells][T] float32 time-contiguous -> out_dev [n_cells][n_doy][P] float64 */
+int hdp_thresholds_f32_dev(const hdp_threshold_plan *plan, const float *x_dev,
+                           int64_t n_cells, double *out_dev, void *stream);
+
+/* Host buffers, arbitrary element strides (in elements) for cell and time. */
+int hdp_thresholds_f32(const float *x, int64_t n_cells, int64_t T,
+                       int64_t stride_cell, int64_t stride_time,
+                       const int64_t *time_index, int64_t n_doy, int64_t S,
+                       const int32_t *cols, int64_t W,
+                       const double *q, int64_t P, double *out /* [n_cells][n_doy][P] */);
+
+/* Literal gufunc operands (threshold.py:53-57): win [n_doy][B] int64 gather table
+ * (negative indices wrap like NumPy).  Slow general path: one full sort per window;
+ * used for unit-level parity and as an independent check of the plan kernel. */
+int hdp_percentiles_table_f32(const float *x, int64_t n_cells, int64_t T,
+                              int64_t stride_cell, int64_t stride_time,
+                              const int64_t *win, int64_t n_doy, int64_t B,
+                              const double *q, int64_t P, double *out);
+
+/* ---- metrics: replaces compute_heatwave_metrics (metric.py:304-341) --------- */
+
+/*
+ * Plan = tables shared by every cell:
+ *   doy_map [T]     int64  threshold row of each time step (metric.py:265-277)
+ *   defs    [D][3]  int64  (min_duration, max_break, max_subs)  (metric.py:376-379)
+ *   north, south [Y][2] int64 season [start,end) time indices per hemisphere
+ *                          (metric.py:221-243; must be increasing and disjoint)
+ */
+typedef struct hdp_metrics_plan hdp_metrics_plan;
+
+int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy,
+                            const int64_t *defs, int64_t D,
+                            const int64_t *north, const int64_t *south, int64_t Y,
+                            int64_t P, hdp_metrics_plan **plan_out);
+int hdp_metrics_plan_destroy(hdp_metrics_plan *plan);
+/* Row pitch (in int16 elements) of the device output: Y rounded up to 4. */
+int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan);
+
+/*
+ * x_dev [n_cells][T] f32, thr_dev [n_thr_cells][n_doy][P] f64 where the thresholds of
+ * cell c are row (c % n_thr_cells) (ensemble members share their cell's thresholds
+ * when series are ordered member-major), is_south_dev [n_cells] u8 ->
+ * out_dev [4][P][D][n_cells][Ypitch] int16, metric order HWF, HWN, HWD, HWA
+ * (metric.py:336-340).  Values are bounded by the season length (< 32768).
+ */
+int hdp_metrics_f32_dev(const hdp_metrics_plan *plan, const float *x_dev,
+                        const double *thr_dev, int64_t n_thr_cells,
+                        const uint8_t *is_south_dev, int64_t n_cells,
+                        int16_t *out_dev, void *stream);
+
+/* Host buffers; out [P][D][n_cells][4][Y] int16 (the reference's block layout,
+ * metric.py:368-369, narrowed; the Python adapter widens to int64). */
+int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T,
+                    int64_t stride_cell, int64_t stride_time,
+                    const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                    const int64_t *doy_map, const int64_t *defs, int64_t D,
+                    const int64_t *north, const int64_t *south,
+                    const uint8_t *is_south, int64_t Y, int16_t *out);
+
+/* ---- unit-level mirrors of the njit helpers (for the known-answer tests) ---- */
+
+/* metric.py:11-60: hot [n_series][T] u8 -> ids [n_series][T] int64 */
+int hdp_index_heatwaves(const uint8_t *hot, int64_t n_series, int64_t T,
+                        int64_t min_duration, int64_t max_break, int64_t max_subs,
+                        int64_t *ids);
+/* metric.py:63-172: ids [n_series][T] int64, ranges [Y][2] (any order, may overlap)
+ * -> out [n_series][4][Y] int64 (HWF,HWN,HWD,trunc(HWA)) and hwa [n_series][Y] f64 */
+int hdp_season_metrics(const int64_t *ids, int64_t n_series, int64_t T,
+                       const int64_t *ranges, int64_t Y, int64_t *out, double *hwa);
+/* metric.py:280-301: measure [n_series][T] f32, thr [n_series][n_doy] f64 -> hot u8 */
+int hdp_indicate_hot_days(const float *measure, int64_t n_series, int64_t T,
+                          const double *thr, int64_t n_doy, const int64_t *doy_map,
+                          uint8_t *hot);
+
+/* ---- synthetic inputs for bench.py (utils.py:61-78 formula) ---- */
+/* x_dev [n_cells][T]: 20 + 2 sin(2 pi (beta + t)/365) - 10|lat|/90 + noise + trend,
+ * beta = 90 (south) / 270 (north), noise = u(seed,cell,t) * noise_scale,
+ * trend = t * trend_per_day.  lat_dev [n_cells] f32. */
+int hdp_generate_series_dev(float *x_dev, int64_t n_cells, int64_t T, int64_t cell_offset,
+                            const float *lat_dev, uint64_t seed, float noise_scale,
+                            float trend_per_day, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDP_HIP_H */

@@ -1,0 +1,282 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+reference-generated golden fixtures.  Integers bit-exact; thresholds bit-exact against
+the oracle (same float64 operation order) and <= 1e-6 relative (north_star tolerance)
+against the fixtures that went through NumPy's quantile."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from hdp_amd import calendar as cal  # noqa: E402
+from hdp_amd import core  # noqa: E402
+from oracle import hdp_oracle as orc  # noqa: E402
+
+REL_TOL = 1e-6  # north_star: "within 1e-6 relative for float thresholds"
+
+
+def same_f64(a, b):
+    """bit-level equality up to NaN payload and the sign of zero"""
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+# ---- known-answer tests of the reference, through the C ABI --------------------------------
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "reference_kat.json")))
+
+
+def test_index_heatwaves_reference_kat(kat):
+    for case in kat["index_heatwaves"]:
+        got = core.index_heatwaves(np.array(case["hot"], dtype=bool), *case["definition"])
+        assert np.array_equal(got, case["expected"]), case["case"]
+
+
+def test_season_metrics_reference_kat(kat):
+    for case in kat["season_metrics"]:
+        fn = getattr(core, case["function"])
+        got = fn(np.array(case["ids"]), np.array(case["ranges"]))
+        if case["function"] == "heatwave_average":
+            assert np.allclose(got, case["expected"], rtol=1e-15, atol=0), case
+        else:
+            assert np.array_equal(got, case["expected"]), case
+
+
+def test_random_series_vs_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "metric_random.npz"))
+    off, roff = g["offsets"], g["range_offsets"]
+    for i in range(off.size - 1):
+        hot = g["hot"][off[i]:off[i + 1]].astype(bool)
+        ids = core.index_heatwaves(hot, *g["definitions"][i])
+        assert np.array_equal(ids, g["ids"][off[i]:off[i + 1]]), i
+        rng = g["ranges"][roff[i]:roff[i + 1]]
+        sl = slice(roff[i], roff[i + 1])
+        assert np.array_equal(core.heatwave_frequency(ids, rng), g["hwf"][sl])
+        assert np.array_equal(core.heatwave_number(ids, rng), g["hwn"][sl])
+        assert np.array_equal(core.heatwave_duration(ids, rng), g["hwd"][sl])
+        assert np.array_equal(core.heatwave_average(ids, rng), g["hwa"][sl])
+
+
+def test_empty_season_raises_like_reference():
+    with pytest.raises(ValueError):
+        core.heatwave_duration(np.zeros(10, dtype=np.int64), np.array([[3, 3]]))
+
+
+# ---- thresholds ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("tag", ["full3", "ragged"])
+def test_thresholds_small_workflow(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "small_workflow.npz"))
+    s, e = g[f"{tag}_range"]
+    dates = orc.noleap_date_range(str(s), str(e))
+    ti, cols = cal.window_columns(dates, 7)
+    x = g[f"{tag}_baseline"]
+    got = core.compute_percentiles(x, ti, cols, g["percentiles"])
+    want = orc.compute_thresholds_cells(x, g[f"{tag}_window"], g["percentiles"])
+    assert same_f64(got, want)                                   # vs oracle: bit-exact
+    np.testing.assert_allclose(got, g[f"{tag}_thresholds"], rtol=REL_TOL, atol=0)  # vs reference run
+    tab = core.compute_percentiles_table(x, g[f"{tag}_window"], g["percentiles"])
+    assert same_f64(tab, want)
+
+
+def test_thresholds_c1_generator_defaults(golden_dir):
+    g = np.load(os.path.join(golden_dir, "c1_workflow.npz"))
+    for tag, noise in (("plain", False), ("noise", True)):
+        base, lon, lat, dates = orc.generate_control(add_noise=noise)
+        x = base.astype(np.float32).reshape(-1, base.shape[-1])
+        ti, cols = cal.window_columns(dates, 7)
+        got = core.compute_percentiles(x, ti, cols, g["percentiles"])
+        want = orc.compute_thresholds_cells(x, cal.expand_window_table(ti, cols), g["percentiles"])
+        assert same_f64(got, want)
+        np.testing.assert_allclose(got.reshape(g[f"{tag}_thresholds"].shape), g[f"{tag}_thresholds"],
+                                   rtol=REL_TOL, atol=0)
+
+
+@pytest.mark.parametrize("q", [
+    [0.0, 1.0], [0.5], [0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 1.0], list(np.arange(0.9, 1, 0.01)),
+    [0.999, 0.001], [1 / 3], list(np.linspace(0.80, 0.99, 20)),
+])
+def test_thresholds_arbitrary_quantiles(q):
+    rng = np.random.default_rng(11)
+    dates = orc.noleap_date_range("2001-01-01", "2006-12-31")
+    x = rng.normal(10, 5, size=(7, dates.size)).astype(np.float32)
+    ti, cols = cal.window_columns(dates, 7)
+    want = orc.compute_thresholds_cells(x, cal.expand_window_table(ti, cols), q)
+    assert same_f64(core.compute_percentiles(x, ti, cols, q), want)
+    assert same_f64(core.compute_percentiles_table(x, cal.expand_window_table(ti, cols), q), want)
+
+
+@pytest.mark.parametrize("radius", [0, 1, 3, 10])
+def test_thresholds_other_window_sizes(radius):
+    rng = np.random.default_rng(radius)
+    dates = orc.noleap_date_range("2001-01-01", "2004-12-31")
+    x = rng.normal(size=(3, dates.size)).astype(np.float32)
+    ti, cols = cal.window_columns(dates, radius)
+    q = [0.05, 0.5, 0.9, 0.99]
+    want = orc.compute_thresholds_cells(x, cal.expand_window_table(ti, cols), q)
+    assert same_f64(core.compute_percentiles(x, ti, cols, q), want)
+
+
+def test_thresholds_special_values():
+    """NaN anywhere in a window -> all quantiles NaN; infinities follow numba's heuristics;
+    duplicated samples; -1 padding samples the last time step."""
+    rng = np.random.default_rng(5)
+    dates = orc.noleap_date_range("2001-01-01", "2003-08-20")   # ragged: -1 padding
+    T = dates.size
+    x = rng.normal(size=(6, T)).astype(np.float32)
+    x[0, 400] = np.nan
+    x[1, 10] = np.inf
+    x[2, 20] = -np.inf
+    x[2, 21] = -np.inf
+    x[3, :] = 1.5                      # all duplicates
+    x[4, :] = np.round(x[4, :])        # many ties
+    x[5, T - 1] = np.inf               # the padded sample
+    ti, cols = cal.window_columns(dates, 7)
+    q = [0.0, 0.3, 0.9, 0.95, 1.0]
+    with np.errstate(invalid="ignore"):
+        want = orc.compute_thresholds_cells(x, cal.expand_window_table(ti, cols), q)
+    got = core.compute_percentiles(x, ti, cols, q)
+    assert same_f64(got, want)
+    assert np.isnan(got[0]).any() and not np.isnan(got[0]).all()
+    assert same_f64(core.compute_percentiles_table(x, cal.expand_window_table(ti, cols), q), want)
+
+
+def test_thresholds_bad_quantile_raises_like_numba():
+    dates = orc.noleap_date_range("2001-01-01", "2002-12-31")
+    x = np.zeros((1, dates.size), dtype=np.float32)
+    ti, cols = cal.window_columns(dates, 7)
+    with pytest.raises(ValueError, match="Quantiles must be in the range"):
+        core.compute_percentiles(x, ti, cols, [0.5, 1.5])
+
+
+def test_thresholds_strided_layouts():
+    """time-major [T, cells] input (CMIP layout) gives the same result as time-contiguous."""
+    rng = np.random.default_rng(8)
+    dates = orc.noleap_date_range("2001-01-01", "2004-12-31")
+    xt = rng.normal(size=(dates.size, 9)).astype(np.float32)     # [T, cells]
+    ti, cols = cal.window_columns(dates, 7)
+    q = [0.9, 0.95]
+    a = core.compute_percentiles(xt.T, ti, cols, q)
+    b = core.compute_percentiles(np.ascontiguousarray(xt.T), ti, cols, q)
+    assert same_f64(a, b)
+
+
+def test_thresholds_many_samples_per_doy():
+    """S = 120 (two registers per lane) and S = 300 (ensemble-like: members concatenated)."""
+    rng = np.random.default_rng(21)
+    for years in (120, 300):
+        dates = orc.noleap_date_range("0001-01-01", f"{years:04d}-12-31")
+        x = rng.normal(size=(2, dates.size)).astype(np.float32)
+        ti, cols = cal.window_columns(dates, 7)
+        q = [0.9, 0.99]
+        got = core.compute_percentiles(x, ti, cols, q)
+        # oracle on a subset of rows (full table is slow in pure Python)
+        rows = [0, 1, 100, 357, 358, 364]
+        win = cal.expand_window_table(ti, cols)[rows]
+        want = orc.compute_thresholds_cells(x, win, q)
+        assert same_f64(got[:, rows], want)
+
+
+# ---- metrics ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("tag", ["full3", "ragged"])
+def test_metrics_small_workflow(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "small_workflow.npz"))
+    got = core.compute_heatwave_metrics(g[f"{tag}_measure"], g[f"{tag}_thresholds"], g[f"{tag}_doy_map"],
+                                        g["definitions"], g[f"{tag}_north"], g[f"{tag}_south"],
+                                        g[f"{tag}_is_south"])
+    assert got.dtype == np.int16
+    assert np.array_equal(got.astype(np.int64), g[f"{tag}_metrics"])
+
+
+def test_metrics_c1_generator_defaults(golden_dir):
+    g = np.load(os.path.join(golden_dir, "c1_workflow.npz"))
+    for tag, noise in (("plain", False), ("noise", True)):
+        meas, lon, lat, dates = orc.generate_warming(add_noise=noise)
+        m = meas.astype(np.float32).reshape(-1, meas.shape[-1])
+        is_south = np.repeat((lat < 0)[None, :], meas.shape[0], axis=0).reshape(-1)
+        thr = g[f"{tag}_thresholds"].reshape(m.shape[0], 365, -1)
+        got = core.compute_heatwave_metrics(m, thr, g["doy_map"], g["definitions"], g["north"], g["south"],
+                                            is_south)
+        assert np.array_equal(got.astype(np.int64).reshape(g[f"{tag}_metrics"].shape), g[f"{tag}_metrics"])
+
+
+def test_metrics_many_definitions_and_percentiles():
+    """P*D = 240 > 64: several lane groups per series; shared thresholds across members."""
+    rng = np.random.default_rng(2)
+    dates = orc.noleap_date_range("2001-01-01", "2006-12-31")
+    T = dates.size
+    n_cells, members = 3, 2
+    x = rng.normal(0, 1, size=(members * n_cells, T)).astype(np.float32)
+    P = 20
+    thr = np.sort(rng.normal(0.8, 0.5, size=(n_cells, 365, P)), axis=2)
+    defs = [[a, b, b] for a in (3, 4, 5, 6) for b in (0, 1, 2)]
+    doy_map = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    is_south = np.array([0, 1, 0] * members, dtype=np.uint8)
+    got = core.compute_heatwave_metrics(x, thr, doy_map, defs, north, south, is_south)
+    want = orc.compute_metrics_cells(x, np.concatenate([thr] * members), doy_map, defs, north, south, is_south)
+    assert np.array_equal(got.astype(np.int64), want)
+
+
+def test_metrics_edge_series():
+    """never hot / always hot (one run spanning every season) / NaN measure / NaN threshold /
+    exact ties (strict >)."""
+    dates = orc.noleap_date_range("2001-01-01", "2005-12-31")
+    T = dates.size
+    rng = np.random.default_rng(9)
+    x = rng.normal(size=(6, T)).astype(np.float32)
+    thr = np.zeros((6, 365, 2))
+    thr[..., 1] = 1.0
+    x[0] = -5          # never hot
+    x[1] = 5           # always hot
+    x[2, ::7] = np.nan  # NaN days are not hot
+    thr[3, 100:200, :] = np.nan
+    x[4] = 1.0         # equals threshold p=1 -> not hot (strict), hot for p=0
+    defs = [[3, 0, 0], [1, 1, 1], [0, 0, 1], [2, 3, 2], [5, 1, 4]]
+    doy_map = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    is_south = np.array([0, 1, 0, 1, 0, 1], dtype=np.uint8)
+    got = core.compute_heatwave_metrics(x, thr, doy_map, defs, north, south, is_south)
+    want = orc.compute_metrics_cells(x, thr, doy_map, defs, north, south, is_south)
+    assert np.array_equal(got.astype(np.int64), want)
+    assert got[0, :, 0].max() == 0 and got[0, 0, 1, 0].min() >= 61
+
+
+def test_indicate_hot_days_matches_oracle():
+    rng = np.random.default_rng(4)
+    dates = orc.noleap_date_range("2001-01-01", "2002-12-31")
+    x = rng.normal(size=dates.size).astype(np.float32)
+    thr = rng.normal(size=365)
+    thr[5] = float(x[5])  # exact tie
+    dm = cal.build_doy_map(dates)
+    assert np.array_equal(core.indicate_hot_days(x, thr, dm), orc.indicate_hot_days(x, thr, dm))
+
+
+def test_end_to_end_c2_shape_sampled():
+    """3650 d x 24 cells, 10 percentiles x 6 definitions: HIP thresholds -> HIP metrics
+    against oracle thresholds -> oracle metrics on the same seeded inputs."""
+    rng = np.random.default_rng(1)
+    dates = orc.noleap_date_range("2001-01-01", "2010-12-31")
+    T = dates.size
+    n = 24
+    t = np.arange(T)
+    base = (15 + 8 * np.sin(2 * np.pi * (t[None, :] - 110) / 365) + rng.normal(0, 2.5, size=(n, T))).astype(np.float32)
+    meas = (base + 0.5 + t[None, :] / 36500.0 + rng.normal(0, 1.0, size=(n, T))).astype(np.float32)
+    q = np.arange(0.9, 1, 0.01)
+    defs = [[3, 0, 0], [3, 1, 1], [4, 0, 0], [4, 1, 1], [5, 0, 0], [5, 1, 1]]
+    ti, cols = cal.window_columns(dates, 7)
+    thr = core.compute_percentiles(base, ti, cols, q)
+    sample = [0, 5, 23]
+    want_thr = orc.compute_thresholds_cells(base[sample], cal.expand_window_table(ti, cols), q)
+    assert same_f64(thr[sample], want_thr)
+    doy_map = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    is_south = (np.arange(n) % 2).astype(np.uint8)
+    got = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
+    want = orc.compute_metrics_cells(meas[sample], thr[sample], doy_map, defs, north, south, is_south[sample])
+    assert np.array_equal(got[:, :, sample].astype(np.int64), want)
