@@ -25,7 +25,7 @@ def test_reflected_upper_edge_and_first_occurrence_order():
     ti, cols = cal.window_columns(dates, 7)
     assert ti[0, 0] == 0 and dates[0].dayofyr == 74          # row 0 is the first timestamp's doy
     # window index w gathers row d + r - w; past the end it is reflected to n_doy - (d + r - w)
-    assert list(cols[364]) == [358, 359, 360, 361, 362, 363, 0, 364, 363, 362, 361, 360, 359, 358, 357]
+    assert list(cols[364]) == [359, 360, 361, 362, 363, 364, 0, 364, 363, 362, 361, 360, 359, 358, 357]
     # row 364 of a 365-row table gathers rows {0 (once), 364..357} and the reflected 358..364
     full = cal.datetimes_to_windows(dates, 7)
     assert np.array_equal(full, orc.datetimes_to_windows(dates, 7))
