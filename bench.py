@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""bench.py -- grid-cell-days/sec of compute_thresholds + compute_group_metrics on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|tiny]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in
+HBM: the thresholds kernel over the baseline series and the metrics kernel over the measure
+series of every grid cell a rank owns.  Grid cells are independent, so ranks shard them with
+no data-path collective (weak scaling: every rank processes the full per-GPU workload); the
+RCCL all-gather that reassembles the metrics Dataset is exercised and reported separately
+(`allgather`), never inside `value`.
+
+torch is used only as plumbing here (process group, barrier, the all-gather, device buffers
+whose raw pointers go to the C ABI).  The kernels are launched on torch's current stream and
+timed there with HIP events (hdp_event_*), which is what `roofline.achieved` is computed from.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+HBM_COPY_GBS = 6290.0       # measured float4 copy ceiling, same table
+
+CONFIGS = {
+    # name: (years, n_lat, n_lon)
+    "c3": (100, 720, 1440),   # BASELINE.json configs[2]: 36500 d x 720 x 1440, the config the target is quoted on
+    "c2": (10, 180, 360),     # configs[1]: 3650 d x 180 x 360
+    "tiny": (10, 16, 32),
+}
+PERCENTILES = np.arange(0.9, 1.0, 0.01)                                   # 10 (README.md:48)
+DEFINITIONS = [[3, 0, 0], [3, 1, 1], [4, 0, 0], [4, 1, 1], [5, 0, 0], [5, 1, 1]]  # 6 (README.md:51)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=os.environ.get("HDP_BENCH_CONFIG", "c3"), choices=sorted(CONFIGS))
+    ap.add_argument("--cells", type=int, default=0, help="override the number of grid cells per rank (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
+    ap.add_argument("--mem-fraction", type=float, default=0.88)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from hdp_amd import _lib, calendar as cal, core, utils
+
+    lib = _lib.ensure_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    years, n_lat, n_lon = CONFIGS[args.config]
+    T = years * 365
+    cells_rank = args.cells if args.cells > 0 else n_lat * n_lon   # weak scaling: full grid per rank
+    P, D = PERCENTILES.size, len(DEFINITIONS)
+
+    # ---- host tables (the reference builds the same ones in Python: threshold.py:125, metric.py:410-416)
+    dates = utils.noleap_date_range("2000-01-01", f"{2000 + years - 1}-12-31")
+    time_index, cols = cal.window_columns(dates, 7)
+    doy_map = cal.build_doy_map(dates)
+    north, south, season_years = cal.hemisphere_season_tables(dates)
+    Y = north.shape[0]
+    n_doy = time_index.shape[0]
+    tplan = core.ThresholdPlan(time_index, cols, PERCENTILES, T)
+    mplan = core.MetricsPlan(doy_map, n_doy, DEFINITIONS, north, south, P)
+    Yp = mplan.year_pitch
+
+    # ---- bands: the largest equal split of this rank's cells whose buffers fit in HBM ----------------
+    per_cell = 2 * T * 4 + n_doy * P * 8 + 4 * P * D * Yp * 2 + 4 + 1
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    budget = int(free_b * args.mem_fraction)
+    n_bands = 1
+    while (cells_rank + n_bands - 1) // n_bands * per_cell > budget:
+        n_bands += 1
+    bc = (cells_rank + n_bands - 1) // n_bands
+    cells_rank_eff = bc * n_bands   # equal bands (== cells_rank for the named configs)
+
+    def raw(nbytes):
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+
+    xb, xm = raw(bc * T * 4), raw(bc * T * 4)
+    thr = raw(bc * n_doy * P * 8)
+    out = torch.empty(4 * P * D * bc * Yp, dtype=torch.int16, device=dev)
+    # latitude of every cell of this rank's grid, row-major (lat, lon); band b owns cells [b*bc, (b+1)*bc)
+    lat_axis = np.linspace(-90.0, 90.0, n_lat)
+    cell_ids = np.arange(cells_rank_eff) % (n_lat * n_lon)
+    lat_cells = lat_axis[cell_ids // n_lon].astype(np.float32)
+    lat_dev = torch.from_numpy(lat_cells[:bc].copy()).to(dev)
+    south_dev = [torch.from_numpy((lat_cells[b * bc:(b + 1) * bc] < 0).astype(np.uint8)).to(dev)
+                 for b in range(n_bands)]
+
+    # synthetic inputs, generated on the device (reference generator formula + hashed noise):
+    # baseline = control, measure = control + warming trend (hdp/utils.py:41: t / (365*100))
+    seed = 0
+    _lib.check(lib.hdp_generate_series_dev(xb.data_ptr(), bc, T, rank * cells_rank_eff, lat_dev.data_ptr(),
+                                           seed, 0.7, 0.0, stream))
+    _lib.check(lib.hdp_generate_series_dev(xm.data_ptr(), bc, T, rank * cells_rank_eff, lat_dev.data_ptr(),
+                                           seed + 1, 0.7, 1.0 / 36500.0, stream))
+    torch.cuda.synchronize(dev)
+
+    ev = [[lib.hdp_event_create() for _ in range(3)] for _ in range(n_bands)]
+    t_thr, t_met = [], []
+
+    def step(record):
+        for b in range(n_bands):
+            e0, e1, e2 = ev[b]
+            lib.hdp_event_record(e0, stream)
+            tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
+            lib.hdp_event_record(e1, stream)
+            mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[b].data_ptr(), bc, out.data_ptr(), stream)
+            lib.hdp_event_record(e2, stream)
+            if record:
+                ms = np.zeros(1, dtype=np.float32)
+                p = ms.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_float))
+                _lib.check(lib.hdp_event_elapsed_ms(e0, e1, p)); t_thr.append(float(ms[0]))
+                _lib.check(lib.hdp_event_elapsed_ms(e1, e2, p)); t_met.append(float(ms[0]))
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1e3 / max(1, args.steps)
+    cell_days_step = 2.0 * cells_rank_eff * T * world   # thresholds pass + metrics pass, all ranks
+    value = cell_days_step / (ms_per_step * 1e-3)
+
+    # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch time --------
+    bytes_thr = bc * (4 * T + 8 * n_doy * P)
+    bytes_met = bc * (4 * T + 8 * n_doy * P + 2 * 4 * Y * P * D)          # int16 metrics
+    ms_thr, ms_met = float(np.mean(t_thr)), float(np.mean(t_met))
+    kern = {
+        "thresholds_kernel": {"ms_per_launch": ms_thr, "algorithmic_bytes": bytes_thr,
+                              "GBps": bytes_thr / ms_thr / 1e6, "frac_hbm": bytes_thr / ms_thr / 1e6 / HBM_PEAK_GBS,
+                              "cell_days_per_s": bc * T / (ms_thr * 1e-3)},
+        "metrics_kernel": {"ms_per_launch": ms_met, "algorithmic_bytes": bytes_met,
+                           "GBps": bytes_met / ms_met / 1e6, "frac_hbm": bytes_met / ms_met / 1e6 / HBM_PEAK_GBS,
+                           "cell_days_per_s": bc * T / (ms_met * 1e-3)},
+    }
+    dom = "thresholds_kernel" if ms_thr >= ms_met else "metrics_kernel"
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": kern[dom]["frac_hbm"], "traffic": None,
+                "both_kernels_frac": (bytes_thr + bytes_met) / (ms_thr + ms_met) / 1e6 / HBM_PEAK_GBS,
+                "measured_copy_ceiling": HBM_COPY_GBS}
+
+    # ---- RCCL all-gather of the metrics (reassembly step of north_star), reported separately ------------
+    allgather = None
+    if world > 1:
+        total_c4 = 4 * P * D * (n_lat * n_lon) * Yp              # the C3/C4 grid's int16 metrics, elements
+        share = min(out.numel(), total_c4 // 8)                   # the per-GPU shard of config 4
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        share = int(min(share, free_b * 0.8 / 2 / world))
+        gathered = torch.empty(share * world, dtype=torch.int16, device=dev)
+        dist.all_gather_into_tensor(gathered, out[:share])
+        fence()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            dist.all_gather_into_tensor(gathered, out[:share])
+        fence()
+        dt = (time.perf_counter() - t1) / reps
+        allgather = {"bytes_per_rank": share * 2, "ms": dt * 1e3,
+                     "recv_GBps_per_gpu": share * 2 * (world - 1) / dt / 1e9}
+        del gathered
+
+    # ---- CPU baseline: the C restatement of the reference algorithm on a bounded sample, rank 0 only ----
+    cpu = None
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import c_oracle
+        cores = c_oracle.max_threads()
+        win = cal.expand_window_table(time_index, cols)
+        xb_h = lambda n: xb[: n * T * 4].cpu().numpy().view(np.float32).reshape(n, T)  # noqa: E731
+        xm_h = lambda n: xm[: n * T * 4].cpu().numpy().view(np.float32).reshape(n, T)  # noqa: E731
+        n0 = min(bc, cores)
+        tc = time.perf_counter()
+        th0 = c_oracle.thresholds(xb_h(n0), win, PERCENTILES)
+        hemi0 = (lat_cells[:n0] < 0).astype(np.uint8)
+        c_oracle.metrics(xm_h(n0), th0, doy_map, DEFINITIONS, north, south, hemi0)
+        per_round = time.perf_counter() - tc
+        rounds = int(max(1, min(64, args.cpu_seconds / max(per_round, 1e-3))))
+        ns = min(bc, n0 * rounds)
+        tc = time.perf_counter()
+        th_cpu = c_oracle.thresholds(xb_h(ns), win, PERCENTILES)
+        hemi = (lat_cells[:ns] < 0).astype(np.uint8)
+        met_cpu = c_oracle.metrics(xm_h(ns), th_cpu, doy_map, DEFINITIONS, north, south, hemi)
+        cpu_s = time.perf_counter() - tc
+        cpu = {"value": 2.0 * ns * T / cpu_s, "unit": "cell-days/s", "cores": cores, "kind": "port",
+               "sample": f"first {ns} cells of band 0 of the same workload (T={T}, P={P}, D={D}), both passes, "
+                         f"{cpu_s:.1f} s; oracle/hdp_oracle.c (reference algorithm restated in C, OpenMP over cells)"}
+        # the same sample doubles as a parity spot-check of what the timed kernels produced (band 0 flags)
+        tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
+        mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[0].data_ptr(), bc, out.data_ptr(), stream)
+        torch.cuda.synchronize(dev)
+        th_gpu = thr[: ns * n_doy * P * 8].cpu().numpy().view(np.float64).reshape(ns, n_doy, P)
+        out_gpu = out.view(4, P * D, bc, Yp)[:, :, :ns, :Y].cpu().numpy()
+        met_gpu = np.transpose(out_gpu.reshape(4, P, D, ns, Y), (1, 2, 3, 0, 4)).astype(np.int64)
+        parity = {"cells": ns, "thresholds_bit_exact": bool(np.array_equal(th_gpu, th_cpu)),
+                  "metrics_bit_exact": bool(np.array_equal(met_gpu, met_cpu))}
+
+    if rank == 0:
+        line = {
+            "metric": "grid-cell-days/sec for compute_thresholds+compute_group_metrics",
+            "value": value, "unit": "cell-days/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {T} d x {n_lat} x {n_lon} fp32, {P} percentiles x {D} definitions, "
+                                   f"window radius 7, noleap, per GPU",
+                       "cells_per_gpu": int(cells_rank_eff), "T": T, "percentiles": P, "definitions": D,
+                       "seasons": int(Y), "resident_bands_per_step": n_bands, "cells_per_band": int(bc),
+                       "sharding": "independent grid cells per rank, no data-path collective"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "allgather": allgather,
+            "parity_sample": parity, "device": _lib.device_info(),
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
