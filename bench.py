@@ -120,22 +120,22 @@ def main():
                                            seed + 1, 0.7, 1.0 / 36500.0, stream))
     torch.cuda.synchronize(dev)
 
-    ev = [[lib.hdp_event_create() for _ in range(3)] for _ in range(n_bands)]
+    import ctypes
+    n_ev_steps = args.steps
+    ev = [[[lib.hdp_event_create() for _ in range(3)] for _ in range(n_bands)] for _ in range(n_ev_steps)]
     t_thr, t_met = [], []
 
-    def step(record):
+    def step(k):
+        """k >= 0: timed step k (events recorded, read back after the timed region); k < 0: warm-up"""
         for b in range(n_bands):
-            e0, e1, e2 = ev[b]
-            lib.hdp_event_record(e0, stream)
+            if k >= 0:
+                lib.hdp_event_record(ev[k][b][0], stream)
             tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
-            lib.hdp_event_record(e1, stream)
+            if k >= 0:
+                lib.hdp_event_record(ev[k][b][1], stream)
             mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[b].data_ptr(), bc, out.data_ptr(), stream)
-            lib.hdp_event_record(e2, stream)
-            if record:
-                ms = np.zeros(1, dtype=np.float32)
-                p = ms.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_float))
-                _lib.check(lib.hdp_event_elapsed_ms(e0, e1, p)); t_thr.append(float(ms[0]))
-                _lib.check(lib.hdp_event_elapsed_ms(e1, e2, p)); t_met.append(float(ms[0]))
+            if k >= 0:
+                lib.hdp_event_record(ev[k][b][2], stream)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -144,13 +144,19 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step(False)
+        step(-1)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for k in range(args.steps):
+        step(k)
     fence()
     elapsed = time.perf_counter() - t0
+    ms = ctypes.c_float()
+    for k in range(args.steps):
+        for b in range(n_bands):
+            e0, e1, e2 = ev[k][b]
+            _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(ms))); t_thr.append(float(ms.value))
+            _lib.check(lib.hdp_event_elapsed_ms(e1, e2, ctypes.byref(ms))); t_met.append(float(ms.value))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -185,12 +191,13 @@ def main():
         free_b, _ = torch.cuda.mem_get_info(dev)
         share = int(min(share, free_b * 0.8 / 2 / world))
         gathered = torch.empty(share * world, dtype=torch.int16, device=dev)
-        dist.all_gather_into_tensor(gathered, out[:share])
+        g8, o8 = gathered.view(torch.uint8), out[:share].view(torch.uint8)   # RCCL has no int16 type
+        dist.all_gather_into_tensor(g8, o8)
         fence()
         t1 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            dist.all_gather_into_tensor(gathered, out[:share])
+            dist.all_gather_into_tensor(g8, o8)
         fence()
         dt = (time.perf_counter() - t1) / reps
         allgather = {"bytes_per_rank": share * 2, "ms": dt * 1e3,

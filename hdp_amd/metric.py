@@ -1,0 +1,152 @@
+"""Drop-in for ``hdp.metric`` (the hot half): same function names, arguments, output
+variables, dims, coords, dtypes and attrs; the per-(cell, percentile, definition)
+heatwave detection runs in the fused HIP kernel instead of Numba + apply_ufunc loops.
+
+  compute_individual_metrics <- hdp/metric.py:372-506
+  compute_group_metrics      <- hdp/metric.py:509-523
+  index_heatwaves, heatwave_frequency/number/duration/average, indicate_hot_days
+                             <- hdp/metric.py:11-172,280-301 (GPU mirrors, same signatures)
+  get_range_indices, build_doy_map, compute_hemisphere_ranges
+                             <- hdp/metric.py:175-277 (host tables)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import core
+from ._xr import backend, jan1_stamps
+from .calendar import build_doy_map, get_range_indices, hemisphere_season_tables  # noqa: F401
+from .core import (heatwave_average, heatwave_duration, heatwave_frequency, heatwave_number,  # noqa: F401
+                   index_heatwaves, indicate_hot_days)
+from .utils import add_history, get_version
+
+
+def compute_hemisphere_ranges(measure):
+    """metric.py:212-262: int64 [year, end_points, lat, lon] season index table."""
+    xr = backend()
+    north, south, years = hemisphere_season_tables(np.asarray(measure.coords["time"].values))
+    lat = np.asarray(measure.coords["lat"].values)
+    lon = np.asarray(measure.coords["lon"].values)
+    ranges = np.where((lat < 0)[None, None, :, None], south[:, :, None, None], north[:, :, None, None])
+    ranges = np.broadcast_to(ranges, (north.shape[0], 2, lat.size, lon.size)).astype(np.int64)
+    return xr.DataArray(ranges, dims=["year", "end_points", "lat", "lon"],
+                        coords={"year": years, "end_points": ["start", "finish"], "lat": lat, "lon": lon})
+
+
+def compute_heatwave_metrics(measure, threshold, doy_map, min_duration, max_break, max_subs, season_ranges):
+    """metric.py:304-341 for ONE series: -> int64 [4, Y] rows HWF, HWN, HWD, HWA."""
+    seasons = np.asarray(season_ranges, dtype=np.int64).reshape(-1, 2)
+    out = core.compute_heatwave_metrics(np.asarray(measure, dtype=np.float32)[None, :],
+                                        np.asarray(threshold, dtype=np.float64)[None, :, None], doy_map,
+                                        [[min_duration, max_break, max_subs]], seasons, seasons,
+                                        np.zeros(1, dtype=np.uint8))
+    return out[0, 0, 0].astype(np.int64)
+
+
+def compute_individual_metrics(measure, threshold, hw_definitions, include_threshold: bool = True,
+                               check_variables: bool = True):
+    """HWF/HWN/HWD/HWA for one (measure, threshold) pair (metric.py:372-506).
+
+    Output variables are int64 with dims (percentile, definition, <non-time dims of the
+    measure in order>, time) where time holds one Jan-1 stamp per season year."""
+    xr = backend()
+    times = np.asarray(measure.coords["time"].values)
+    if check_variables:
+        assert "hdp_type" in threshold.attrs
+        assert threshold.attrs["hdp_type"] == "threshold"
+        assert threshold.attrs["baseline_variable"] == measure.attrs["baseline_variable"]
+        assert threshold.attrs["baseline_calendar"] == times[0].calendar
+
+    combined_history = ""
+    for label, obj in (("Measure", measure), ("Threshold", threshold)):
+        for entry in obj.attrs.get("history", "").split("\n"):
+            if entry != "":
+                combined_history += f"({label}) {entry}\n"
+
+    north, south, years = hemisphere_season_tables(times)
+    doy_map = build_doy_map(times)
+
+    m_dims = list(measure.dims)
+    other_dims = [d for d in m_dims if d != "time"]
+    # members share their cell's thresholds: process member-major so series c uses row c % n_cells
+    proc_dims = (["member"] if "member" in other_dims else []) + [d for d in other_dims if d != "member"]
+    m_vals = np.asarray(measure.values)
+    m_vals = np.moveaxis(m_vals, [m_dims.index(d) for d in proc_dims + ["time"]], range(len(m_dims)))
+    proc_shape = m_vals.shape[:-1]
+    x2d = m_vals.reshape(-1, m_vals.shape[-1])
+    if x2d.dtype != np.float32:
+        x2d = x2d.astype(np.float32)
+
+    cell_dims = [d for d in proc_dims if d != "member"]
+    t_dims = list(threshold.dims)
+    thr = np.asarray(threshold.values, dtype=np.float64)
+    thr = np.moveaxis(thr, [t_dims.index(d) for d in cell_dims + ["doy", "percentile"]], range(len(t_dims)))
+    n_doy, P = thr.shape[-2], thr.shape[-1]
+    thr3 = np.ascontiguousarray(thr.reshape(-1, n_doy, P))
+
+    lat = np.asarray(measure.coords["lat"].values)
+    shape_cells = [measure.shape[m_dims.index(d)] for d in proc_dims]
+    lat_b = (lat < 0).reshape([-1 if d == "lat" else 1 for d in proc_dims])   # metric.py:249: lat == 0 is north
+    is_south = np.broadcast_to(lat_b, shape_cells).reshape(-1).astype(np.uint8)
+
+    raw = core.compute_heatwave_metrics(x2d, thr3, doy_map, hw_definitions, north, south, is_south)
+    D, Y = len(hw_definitions), north.shape[0]
+    raw = raw.astype(np.int64).reshape((P, D) + tuple(proc_shape) + (4, Y))   # int, as test_workflow.py:57
+    # back to the measure's own dim order
+    src = ["percentile", "definition"] + proc_dims + ["metric", "year"]
+    dst = ["percentile", "definition"] + other_dims + ["metric", "year"]
+    raw = np.moveaxis(raw, [src.index(d) for d in dst], range(len(dst)))
+
+    stamps = np.array(jan1_stamps(years, times[0]), dtype=object)
+    coords = {k: np.asarray(measure.coords[k].values) for k in measure.coords if k != "time" and k in other_dims}
+    coords["time"] = stamps
+    coords["definition"] = [f"{d[0]}-{d[1]}-{d[2]}" for d in hw_definitions]
+    coords["percentile"] = np.asarray(threshold.coords["percentile"].values)
+    out_dims = ["percentile", "definition"] + other_dims + ["time"]
+    m_axis = dst.index("metric")
+    ds = xr.Dataset(
+        {name: xr.DataArray(np.ascontiguousarray(np.take(raw, i, axis=m_axis)), dims=out_dims, coords=coords)
+         for i, name in enumerate(("HWF", "HWN", "HWD", "HWA"))})
+    ds.attrs.update({
+        "description": f"Heatwave metric dataset generated by Heatwave Diagnostics Package (HDP v{get_version()})",
+        "hdp_version": get_version(),
+        "hdp_type": "metric",
+    })
+    ds["HWF"].attrs.update({"units": "heatwave days", "long_name": "Heatwave Frequency",
+                            "description": "Number of days that fall within heatwave during a heatwave season"})
+    ds["HWD"].attrs.update({"units": "heatwave days", "long_name": "Heatwave Duration",
+                            "description": "Length of longest heatwave during a heatwave season"})
+    ds["HWN"].attrs.update({"units": "heatwave events", "long_name": "Heatwave Number",
+                            "description": "Number of distinct heatwaves during a heatwave season"})
+    ds["HWA"].attrs.update({"units": "heatwave events", "long_name": "Heatwave Average",
+                            "description": "Average length of heatwaves during a heatwave season"})
+    ds["percentile"].attrs.update({"range": "(0, 1)"})
+    ds["definition"].attrs.update({
+        "first_number": "Minimum number of consecutively hot days",
+        "second_number": "Maximum number of break days after first wave",
+        "third_number": "Minimum number of consecutively hot days after the break",
+    })
+    for variable in ds:
+        ds[variable].attrs["history"] = combined_history
+        add_history(ds[variable], f"Heatwave metrics generated by HDP v{get_version()}")
+    return ds
+
+
+def compute_group_metrics(measures, thresholds, hw_definitions, include_threshold: bool = False,
+                          check_variables: bool = True):
+    """Every (measure, threshold) pair with matching ``baseline_variable``; variables are
+    renamed ``{measure}.{threshold}.{metric}`` and merged (metric.py:509-523)."""
+    xr = backend()
+    metric_sets = []
+    for measure_name in list(measures.keys()):
+        measure = measures[measure_name]
+        for threshold_name in list(thresholds.keys()):
+            threshold = thresholds[threshold_name]
+            if threshold.attrs["baseline_variable"] == measure.attrs["baseline_variable"]:
+                hw = compute_individual_metrics(measure, threshold, hw_definitions, include_threshold,
+                                                check_variables)
+                metric_sets.append(hw.rename({n: f"{measure_name}.{threshold_name}.{n}" for n in list(hw.keys())}))
+    aggr = xr.merge(metric_sets)
+    aggr.attrs["variable_naming_desc"] = "(heat measure).(threshold used).(heatwave metric)"
+    aggr.attrs["variable_naming_delimeter"] = "."
+    return aggr

@@ -1,0 +1,102 @@
+"""End-to-end drop-in test, modelled on the reference's hdp/tests/test_workflow.py:15-66
+(2x3 grid, control -> thresholds for arange(0.9, 1, 0.01), warming -> metrics for six
+definitions) with the numeric checks the reference lacks added against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import hdp_amd.metric  # noqa: E402
+import hdp_amd.threshold  # noqa: E402
+from hdp_amd import utils  # noqa: E402
+from oracle import hdp_oracle as orc  # noqa: E402
+from tests.helpers import measure_dataset  # noqa: E402
+
+
+def test_full_data_workflow():
+    grid_shape = (2, 3)
+    base, lon, lat, bdates = utils.generate_control_array(grid_shape=grid_shape)
+    baseline_measures = measure_dataset(base, lon, lat, bdates, "temp")
+    percentiles = np.arange(0.9, 1, 0.01)
+    thresholds = hdp_amd.threshold.compute_thresholds(baseline_measures, percentiles=percentiles)
+
+    warm, _, _, mdates = utils.generate_warming_array(grid_shape=grid_shape)
+    hw_definitions = [[3, 0, 0], [3, 1, 1], [4, 2, 0], [4, 1, 3], [5, 0, 1], [5, 1, 4]]
+    test_measures = measure_dataset(warm, lon, lat, mdates, "temp")
+    metrics = hdp_amd.metric.compute_group_metrics(test_measures, thresholds, hw_definitions)
+
+    metrics = metrics.compute()
+    thresholds = thresholds.compute()
+
+    assert (thresholds.percentile.values == percentiles).all()
+    assert len(thresholds.data_vars) == 1
+    thr = thresholds["temp_threshold"]
+    assert tuple(thr.dims) == ("lon", "lat", "doy", "percentile") and thr.dtype == np.float64
+    assert thr.attrs["hdp_type"] == "threshold" and thr.attrs["baseline_variable"] == "temp"
+    assert thr.attrs["baseline_calendar"] == "noleap" and thr.attrs["param_rolling_window_size"] == "7"
+
+    assert list(metrics.definition.values) == ["3-0-0", "3-1-1", "4-2-0", "4-1-3", "5-0-1", "5-1-4"]
+    assert (metrics.percentile.values == percentiles).all()
+    means = metrics.mean()
+    assert means["temp.temp_threshold.HWF"] >= means["temp.temp_threshold.HWD"]
+    assert means["temp.temp_threshold.HWD"] >= means["temp.temp_threshold.HWA"]
+    for var in metrics:
+        assert metrics[var].shape == (metrics.percentile.size, metrics.definition.size, metrics.lon.size,
+                                      metrics.lat.size, metrics.time.size)
+        assert metrics[var].dtype == int
+        if "HWF" in var or "HWD" in var:
+            assert metrics[var].attrs["units"] == "heatwave days"
+        elif "HWN" in var or "HWA" in var:
+            assert metrics[var].attrs["units"] == "heatwave events"
+        else:
+            assert False, var
+    assert metrics.attrs["variable_naming_delimeter"] == "."
+    assert str(metrics.time.values[0]).startswith("2000-01-01")
+
+    # numeric parity the reference's own test does not assert
+    x = base.astype(np.float32).reshape(-1, base.shape[-1])
+    want_thr = orc.compute_thresholds_cells(x, orc.datetimes_to_windows(bdates, 7), percentiles)
+    assert np.array_equal(thr.values.reshape(want_thr.shape), want_thr)
+    m = warm.astype(np.float32).reshape(-1, warm.shape[-1])
+    north, south, _ = orc.hemisphere_ranges(mdates)
+    is_south = np.repeat((lat < 0)[None, :], grid_shape[0], axis=0).reshape(-1)
+    want = orc.compute_metrics_cells(m, want_thr, orc.build_doy_map(mdates), hw_definitions, north, south, is_south)
+    for i, name in enumerate(("HWF", "HWN", "HWD", "HWA")):
+        got = metrics[f"temp.temp_threshold.{name}"].values
+        assert np.array_equal(got.reshape(got.shape[:2] + (-1, got.shape[-1])), want[:, :, :, i, :]), name
+
+
+def test_time_major_and_member_inputs():
+    """CMIP layout (time, lat, lon) and an ensemble 'member' dim: members are concatenated
+    along time for thresholds (threshold.py:114-119) and share thresholds for metrics."""
+    rng = np.random.default_rng(3)
+    dates = utils.noleap_date_range("2001-01-01", "2004-12-31")
+    T, n_lat, n_lon, n_mem = dates.size, 3, 2, 2
+    lat = np.array([-30.0, 0.0, 45.0]); lon = np.array([10.0, 20.0])
+    data = rng.normal(10, 3, size=(n_mem, T, n_lat, n_lon)).astype(np.float32)
+    ds = measure_dataset(data, lon, lat, dates, "tas", dims=("member", "time", "lat", "lon"),
+                         extra_coords={"member": np.arange(n_mem)})
+    q = [0.9, 0.95]
+    thr_ds = hdp_amd.threshold.compute_thresholds(ds, q)
+    thr = thr_ds["tas_threshold"]
+    assert tuple(thr.dims) == ("lat", "lon", "doy", "percentile")
+    # oracle: concatenate members along time per cell
+    cat = np.concatenate([data[m] for m in range(n_mem)], axis=0)          # [n_mem*T, lat, lon]
+    x = np.moveaxis(cat, 0, -1).reshape(-1, n_mem * T)
+    win = orc.datetimes_to_windows(np.concatenate([dates] * n_mem), 7)
+    want_thr = orc.compute_thresholds_cells(x, win, q)
+    assert np.array_equal(thr.values.reshape(want_thr.shape), want_thr)
+
+    defs = [[3, 0, 0], [2, 1, 1]]
+    met = hdp_amd.metric.compute_group_metrics(ds, thr_ds, defs)
+    hwf = met["tas.tas_threshold.HWF"]
+    assert tuple(hwf.dims) == ("percentile", "definition", "member", "lat", "lon", "time")
+    north, south, years = orc.hemisphere_ranges(dates)
+    dm = orc.build_doy_map(dates)
+    for m in range(n_mem):
+        xm = np.moveaxis(data[m], 0, -1).reshape(-1, T)
+        hemi = np.repeat((lat < 0)[:, None], n_lon, axis=1).reshape(-1)
+        want = orc.compute_metrics_cells(xm, want_thr, dm, defs, north, south, hemi)
+        for i, name in enumerate(("HWF", "HWN", "HWD", "HWA")):
+            got = met[f"tas.tas_threshold.{name}"].values[:, :, m]
+            assert np.array_equal(got.reshape(got.shape[:2] + (-1, got.shape[-1])), want[:, :, :, i, :])
