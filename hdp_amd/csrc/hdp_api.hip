@@ -310,7 +310,15 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   }
   auto *pl = new hdp_metrics_plan();
   pl->T = T; pl->n_doy = n_doy; pl->D = D; pl->Y = Y; pl->P = P;
-  pl->Ypitch = (Y + 3) & ~int64_t(3);
+  pl->Ypitch = (Y + 15) & ~int64_t(15);  // 32-byte rows: sector-aligned packed stores
+  int64_t dmax = 1;
+  for (int64_t d = 0; d < D; ++d) dmax = std::max<int64_t>(dmax, dd[3 * d]);
+  pl->dmax = dmax;
+  bool uniform = dmax < (int64_t(1) << 20);
+  for (int h = 0; h < 2 && uniform; ++h)
+    for (int64_t y = 0; y + 1 < Y; ++y)
+      if (ss[h * Y + y + 1].x - ss[h * Y + y].y < dmax + 64) uniform = false;
+  pl->uniform_seasons = uniform;
   hipError_t e = pl->doy_map.upload(dm.data(), dm.size() * 2);
   if (e == hipSuccess) e = pl->defs.upload(dd.data(), dd.size() * 4);
   if (e == hipSuccess) e = pl->seasons.upload(ss.data(), ss.size() * sizeof(int2));

@@ -97,6 +97,8 @@ struct hdp_threshold_plan {
 struct hdp_metrics_plan {
   int64_t T = 0, n_doy = 0, D = 0, Y = 0, P = 0;
   int64_t Ypitch = 0;
+  int64_t dmax = 1;           // max over definitions of max(min_duration, 1)
+  bool uniform_seasons = false;  // consecutive seasons >= dmax + 64 days apart (fast kernel)
   hdp::DevBuf doy_map;   // uint16 [T rounded up to 64]
   hdp::DevBuf defs;      // int32 [D][3]
   hdp::DevBuf seasons;   // int2 [2][Y]  (north, south)

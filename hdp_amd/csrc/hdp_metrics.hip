@@ -23,6 +23,7 @@
 #include "hdp_internal.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace hdp {
 
@@ -32,6 +33,7 @@ struct MetDev {
   const int2 *seasons;      // [2][Y]
   int T, n_doy, D, Y, P, Ypitch, n_groups, np_max, n_doy_pad;
   int seas_bytes, thr_bytes, wave_bytes;  // LDS carve, all multiples of 16
+  int dmax;                                // max over definitions of max(min_duration, 1)
 };
 
 constexpr int kMetWaves = 4;
@@ -110,7 +112,7 @@ __device__ __forceinline__ void process_run(LaneState &st, int s, int e, int min
   }
 }
 
-__global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel(
+__global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_general(
     MetDev md, const float *__restrict__ x, const double *__restrict__ thr, int64_t n_thr_cells,
     const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -226,6 +228,237 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel(
     if (st.open) process_run(st, st.s_open, md.T, min_dur, max_subs, seas, md.Y, out_f, out_n, out_d, out_a);
     while (st.si < md.Y) finalize_season(st, md.Y, out_f, out_n, out_d, out_a);
   }
+}
+
+// ---- fast path: seasons far enough apart that every lane can close a season at the same time ----
+//
+// All lanes of a wave walk the same series, so season boundaries are wave-uniform in time.  When
+// consecutive seasons of a hemisphere are at least dmax + 64 days apart (dmax = largest
+// min_duration; the reference's May-Oct / Nov-Apr tables are ~210 days apart) a season can be
+// finalised for ALL lanes at the first 32-day word starting >= season_end + dmax:
+//   * a hot run still open there that began inside the season is already longer than every
+//     min_duration, so the reference WILL label it (metric.py:44-58: long runs are labelled in
+//     every branch) and its id is known (current id, +1 unless it is a sub-event): its in-season
+//     days are credited now, without committing the state machine, which still runs at the run's end;
+//   * every run processed before that point ends before the next season starts, every run processed
+//     after it either was open (credited above) or lies beyond the season.
+// Season bounds therefore live in SGPRs, the four results are packed 16 seasons per 32-byte
+// sector-aligned store, and the per-run path is branch-free.
+constexpr int kCW = 64;  // 64-day exceedance words per chunk: lane w of a VGPR holds word w
+constexpr int kQB = 8;   // percentiles per stage-A batch
+
+struct ULane {
+  int open, s_open, e_prev;
+  int in_hw, subs, id;
+  int hwf, hwn, hwd, cur, last_id;
+};
+
+__device__ __forceinline__ void credit(ULane &st, int days, int run_id) {
+  // days > 0 of a labelled run with id run_id fall inside the current season
+  const bool first = run_id != st.last_id;
+  st.hwf += days;
+  st.hwn += first ? 1 : 0;
+  st.cur = first ? days : st.cur + days;
+  st.last_id = run_id;
+  st.hwd = max(st.hwd, st.cur);
+}
+
+// branch-free form of the reference state machine for one finished run [s, e)
+__device__ __forceinline__ void run_closed(ULane &st, int s, int e, int min_dur, int max_subs, int sa, int sb) {
+  const bool ge = (e - s) >= min_dur;
+  const bool sub = st.in_hw && (st.subs < max_subs);
+  const bool label = sub || ge;
+  st.subs = sub ? st.subs + 1 : (st.in_hw ? 0 : st.subs);
+  st.id += (ge && !sub) ? 1 : 0;
+  st.in_hw = label ? 1 : 0;
+  const int days = min(e, sb) - max(s, sa);
+  if (label && days > 0) credit(st, days, st.id);
+}
+
+__device__ __forceinline__ void push16(uint32_t (&a)[8], uint32_t v) {
+#pragma unroll
+  for (int i = 0; i < 7; ++i) a[i] = __builtin_amdgcn_alignbit(a[i + 1], a[i], 16);
+  a[7] = (a[7] >> 16) | (v << 16);
+}
+
+__device__ __forceinline__ void store32(int16_t *dst, const uint32_t (&a)[8]) {
+  uint4 *p = reinterpret_cast<uint4 *>(dst);
+  p[0] = make_uint4(a[0], a[1], a[2], a[3]);
+  p[1] = make_uint4(a[4], a[5], a[6], a[7]);
+}
+
+__global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
+    MetDev md, const float *__restrict__ x, const double *__restrict__ thr, int64_t n_thr_cells,
+    const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+
+  // LDS per wave: thr32 [np_max][n_doy_pad] f32 | bits [np_max][kCW] u64
+  unsigned char *wbase = smem + size_t(wave) * md.wave_bytes;
+  float *thr32 = reinterpret_cast<float *>(wbase);
+  unsigned long long *bits64 = reinterpret_cast<unsigned long long *>(wbase + md.thr_bytes);
+  const uint32_t *bits32 = reinterpret_cast<const uint32_t *>(bits64);
+
+  const int64_t task = int64_t(blockIdx.x) * kMetWaves + wave;
+  if (task >= n_cells * md.n_groups) return;  // no workgroup barriers in this kernel
+  const int64_t cell = task / md.n_groups;
+  const int group = int(task % md.n_groups);
+
+  const int PD = md.P * md.D;
+  const int c0 = group * 64;
+  const int combo = c0 + lane;
+  const bool valid = combo < PD;
+  const int p_lo = c0 / md.D;
+  const int p_hi = min(md.P - 1, (min(PD, c0 + 64) - 1) / md.D);
+  const int np = p_hi - p_lo + 1;
+  const int my_p = valid ? combo / md.D : p_lo;
+  const int my_d = valid ? combo % md.D : 0;
+  const int pi = my_p - p_lo;
+
+  {  // thresholds of this series -> LDS as f32 rounded toward -inf
+    const double *tc = thr + (cell % n_thr_cells) * int64_t(md.n_doy) * md.P;
+    for (int d0 = 0; d0 < md.n_doy; d0 += 64) {
+      const int doy = d0 + lane;
+      if (doy < md.n_doy)
+        for (int q = 0; q < np; ++q)
+          thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(doy) * md.P + p_lo + q]);
+    }
+  }
+
+  const int Y = md.Y;
+  const int hemi = __builtin_amdgcn_readfirstlane((int)is_south[cell]);
+  const int2 *seas = md.seasons + (hemi ? Y : 0);  // wave-uniform reads
+  int si = 0;
+  int sa = 0x7fffffff - 1024, sb = 0x7fffffff - 1024;
+  if (Y > 0) {
+    sa = __builtin_amdgcn_readfirstlane(seas[0].x);
+    sb = __builtin_amdgcn_readfirstlane(seas[0].y);
+  }
+
+  const int min_dur = md.defs[my_d * 3 + 0];
+  const int max_break = md.defs[my_d * 3 + 1];
+  const int max_subs = md.defs[my_d * 3 + 2];
+  const int dmax = md.dmax;
+  const int Ypitch_unused = md.Ypitch; (void)Ypitch_unused;
+  const int64_t row = ((int64_t(my_p) * md.D + my_d) * n_cells + cell) * md.Ypitch;
+  const int64_t plane = int64_t(md.P) * md.D * n_cells * md.Ypitch;
+  int16_t *orow = out + row;
+
+  ULane st;
+  st.open = 0; st.s_open = 0; st.e_prev = -(1 << 30);
+  st.in_hw = 0; st.subs = 0; st.id = 0;
+  st.hwf = st.hwn = st.hwd = st.cur = 0; st.last_id = 0;
+  uint32_t af[8], an[8], ad[8], aa[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) af[i] = an[i] = ad[i] = aa[i] = 0;
+
+  // close season `si` (wave-uniform) for every lane
+#define HDP_FINALIZE(CREDIT_OPEN)                                                                   \
+  do {                                                                                              \
+    if ((CREDIT_OPEN) && st.open && st.s_open < sb) {                                               \
+      const bool sub_ = st.in_hw && (st.subs < max_subs);                                           \
+      credit(st, sb - max(st.s_open, sa), st.id + (sub_ ? 0 : 1));                                  \
+    }                                                                                               \
+    const uint32_t hwa_ = st.hwn ? (uint32_t)st.hwf / (uint32_t)st.hwn : 0u; /* == HWF // HWN */    \
+    push16(af, (uint32_t)st.hwf & 0xffffu);                                                         \
+    push16(an, (uint32_t)st.hwn & 0xffffu);                                                         \
+    push16(ad, (uint32_t)st.hwd & 0xffffu);                                                         \
+    push16(aa, hwa_ & 0xffffu);                                                                     \
+    if ((si & 15) == 15 || si == Y - 1) {                                                           \
+      for (int k_ = (si & 15); k_ < 15; ++k_) { /* partial last group: shift the tail down */       \
+        push16(af, 0); push16(an, 0); push16(ad, 0); push16(aa, 0);                                 \
+      }                                                                                             \
+      if (valid) {                                                                                  \
+        int16_t *o_ = orow + (si & ~15);                                                            \
+        store32(o_, af);                                                                            \
+        store32(o_ + plane, an);                                                                    \
+        store32(o_ + 2 * plane, ad);                                                                \
+        store32(o_ + 3 * plane, aa);                                                                \
+      }                                                                                             \
+    }                                                                                               \
+    st.hwf = st.hwn = st.hwd = st.cur = 0;                                                          \
+    st.last_id = 0;                                                                                 \
+    si += 1;                                                                                        \
+    if (si < Y) {                                                                                   \
+      sa = __builtin_amdgcn_readfirstlane(seas[si].x);                                              \
+      sb = __builtin_amdgcn_readfirstlane(seas[si].y);                                              \
+    } else {                                                                                        \
+      sa = sb = 0x7fffffff - 1024;                                                                  \
+    }                                                                                               \
+  } while (0)
+
+  const float *xc = x + cell * int64_t(md.T);
+  const int n_words = (md.T + 63) >> 6;
+
+  for (int w0 = 0; w0 < n_words; w0 += kCW) {
+    const int nw = min(kCW, n_words - w0);
+    // ---- stage A: exceedance words, kQB percentiles at a time; lane w of lo/hi = word w ----------
+    for (int q0 = 0; q0 < np; q0 += kQB) {
+      const int nb = min(kQB, np - q0);
+      uint32_t lo[kQB], hi[kQB];
+#pragma unroll
+      for (int j = 0; j < kQB; ++j) lo[j] = hi[j] = 0;
+#pragma unroll 2
+      for (int w = 0; w < nw; ++w) {
+        const int t = (w0 + w) * 64 + lane;
+        const bool in = t < md.T;
+        const float xv = in ? xc[t] : 0.0f;
+        const int dv = md.doy_map[t];  // table is padded to a multiple of 64
+        const float *tp = thr32 + q0 * md.n_doy_pad + dv;
+#pragma unroll
+        for (int j = 0; j < kQB; ++j) {
+          if (j < nb) {  // wave-uniform
+            const unsigned long long m = __ballot(in && (xv > tp[j * md.n_doy_pad]));
+            // v_cndmask with the (scalar) ballot halves: lane w keeps word w
+            lo[j] = (lane == w) ? (uint32_t)m : lo[j];
+            hi[j] = (lane == w) ? (uint32_t)(m >> 32) : hi[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kQB; ++j)
+        if (j < nb) bits64[(q0 + j) * kCW + lane] = ((unsigned long long)hi[j] << 32) | lo[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- stage B: 32-day half-words, run by run ---------------------------------------------------
+    for (int hw = 0; hw < 2 * nw; ++hw) {
+      const int t0 = w0 * 64 + hw * 32;
+      while (si < Y && sb + dmax <= t0) HDP_FINALIZE(true);  // wave-uniform
+      const uint32_t word = valid ? bits32[pi * (2 * kCW) + hw] : 0u;
+      const bool work = st.open ? (word != 0xffffffffu) : (word != 0u);
+      if (__ballot(work) == 0) continue;
+      int pos = 0;
+      while (true) {
+        if (!st.open) {
+          const uint32_t r = word >> pos;
+          if (r == 0) break;
+          pos += __builtin_ctz(r);
+          st.s_open = t0 + pos;
+          st.open = 1;
+          if (st.s_open - st.e_prev > max_break) st.in_hw = 0;  // metric.py:48-49
+        }
+        const uint32_t rz = (~word) >> pos;
+        if (rz == 0) break;  // the run continues into the next word
+        pos += __builtin_ctz(rz);
+        const int e = t0 + pos;
+        st.open = 0;
+        run_closed(st, st.s_open, e, min_dur, max_subs, sa, sb);
+        st.e_prev = e;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (st.open) {  // a run reaching the end of the record closes at T (metric.py:27: zero padding)
+    run_closed(st, st.s_open, md.T, min_dur, max_subs, sa, sb);
+    st.open = 0;
+  }
+  while (si < Y) HDP_FINALIZE(false);
+#undef HDP_FINALIZE
 }
 
 // device layout [4][P][D][n][Ypitch] -> reference block layout [P][D][n][4][Y]
@@ -383,9 +616,11 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   md.n_groups = (PD + 63) / 64;
   md.np_max = std::min(md.P, 63 / md.D + 2);
   md.n_doy_pad = (md.n_doy + 3) & ~3;
-  const size_t seas_bytes = (size_t(2) * md.Y * sizeof(int2) + 15) & ~size_t(15);
+  md.dmax = (int)plan->dmax;
+  const bool uniform = plan->uniform_seasons && !getenv("HDP_METRICS_GENERAL");
+  const size_t seas_bytes = uniform ? 0 : ((size_t(2) * md.Y * sizeof(int2) + 15) & ~size_t(15));
   const size_t thr_bytes = (size_t(md.np_max) * md.n_doy_pad * 4 + 15) & ~size_t(15);
-  const size_t per_wave = thr_bytes + size_t(md.np_max) * kChunkWords * 8;
+  const size_t per_wave = thr_bytes + size_t(md.np_max) * (uniform ? kCW : kChunkWords) * 8;
   const size_t lds = seas_bytes + kMetWaves * per_wave;
   md.seas_bytes = (int)seas_bytes;
   md.thr_bytes = (int)thr_bytes;
@@ -395,9 +630,10 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   const int64_t tasks = n_cells * md.n_groups;
   const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
   HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
-  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(metrics_kernel),
+  auto kern = uniform ? metrics_kernel_uniform : metrics_kernel_general;
+  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, md, x_dev,
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, md, x_dev,
                      thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;

@@ -280,3 +280,68 @@ def test_end_to_end_c2_shape_sampled():
     got = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
     want = orc.compute_metrics_cells(meas[sample], thr[sample], doy_map, defs, north, south, is_south[sample])
     assert np.array_equal(got[:, :, sample].astype(np.int64), want)
+
+
+def _random_metrics_case(seed, years, n, P, defs, trend=0.0):
+    rng = np.random.default_rng(seed)
+    dates = orc.noleap_date_range("2001-01-01", f"{2000 + years}-12-31")
+    T = dates.size
+    x = (rng.normal(0, 1, size=(n, T)) + trend * np.arange(T)[None, :] / T).astype(np.float32)
+    thr = np.sort(rng.normal(0.6, 0.4, size=(n, 365, P)), axis=2)
+    doy_map = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    is_south = (np.arange(n) % 2).astype(np.uint8)
+    return x, thr, doy_map, defs, north, south, is_south
+
+
+@pytest.mark.parametrize("years", [16, 17, 32, 3])
+def test_metrics_season_count_vs_packed_stores(years):
+    """Y = 16, 32 (exact 16-season store groups), 17 and 3 (partial groups)."""
+    case = _random_metrics_case(years, years, 5, 3, [[3, 0, 0], [2, 1, 1], [6, 2, 0], [1, 0, 3]], trend=2.0)
+    got = core.compute_heatwave_metrics(*case)
+    assert np.array_equal(got.astype(np.int64), orc.compute_metrics_cells(*case))
+
+
+def test_metrics_general_kernel_forced(monkeypatch):
+    """The per-lane lazy-season kernel (used when seasons are too close for the uniform one)."""
+    case = _random_metrics_case(77, 6, 6, 4, [[3, 0, 0], [3, 1, 1], [5, 1, 4], [0, 0, 1]], trend=1.5)
+    want = orc.compute_metrics_cells(*case)
+    monkeypatch.setenv("HDP_METRICS_GENERAL", "1")
+    got_general = core.compute_heatwave_metrics(*case)
+    monkeypatch.delenv("HDP_METRICS_GENERAL")
+    got_uniform = core.compute_heatwave_metrics(*case)
+    assert np.array_equal(got_general.astype(np.int64), want)
+    assert np.array_equal(got_uniform.astype(np.int64), want)
+
+
+def test_metrics_adjacent_and_short_gap_seasons():
+    """User-supplied season tables with touching / nearly touching ranges (general kernel) and
+    with gaps just above the uniform-kernel threshold."""
+    x, thr, doy_map, defs, _, _, is_south = _random_metrics_case(5, 4, 6, 3, [[3, 1, 1], [2, 0, 0], [7, 2, 1]], 2.0)
+    T = x.shape[1]
+    for north, south in (
+        (np.array([[0, 100], [100, 200], [230, 400], [401, T]]), np.array([[10, 50], [50, 51], [60, 700], [700, T]])),
+        (np.array([[5, 100], [171, 300], [371, 600], [700, T]]), np.array([[0, 30], [101, 131], [202, 232], [303, 333]])),
+    ):
+        got = core.compute_heatwave_metrics(x, thr, doy_map, defs, north, south, is_south)
+        want = orc.compute_metrics_cells(x, thr, doy_map, defs, north, south, is_south)
+        assert np.array_equal(got.astype(np.int64), want)
+
+
+def test_metrics_long_min_duration_and_record_end():
+    """min_duration far above typical runs, T a multiple of 64 with a run open at the end."""
+    dates = orc.noleap_date_range("2001-01-01", "2007-12-31")[:2560]
+    T = dates.size
+    rng = np.random.default_rng(31)
+    x = rng.normal(size=(4, T)).astype(np.float32)
+    x[:, -40:] = 9.0
+    x[1, 100:400] = 9.0
+    thr = np.zeros((4, 365, 2)); thr[..., 1] = 0.8
+    defs = [[40, 2, 1], [3, 0, 0], [30, 0, 0]]
+    doy_map = cal.build_doy_map(dates)
+    north = np.array([[120, 273], [485, 638], [850, 1003], [1215, 1368], [1580, 1733], [1945, 2098], [2310, 2463]])
+    south = np.array([[304, 455], [669, 820], [1034, 1185], [1399, 1550], [1764, 1915], [2129, 2280], [2494, T]])
+    is_south = np.array([0, 1, 0, 1], dtype=np.uint8)
+    got = core.compute_heatwave_metrics(x, thr, doy_map, defs, north, south, is_south)
+    want = orc.compute_metrics_cells(x, thr, doy_map, defs, north, south, is_south)
+    assert np.array_equal(got.astype(np.int64), want)
