@@ -34,6 +34,7 @@ struct MetDev {
   int T, n_doy, D, Y, P, Ypitch, n_groups, np_max, n_doy_pad;
   int seas_bytes, thr_bytes, wave_bytes;  // LDS carve, all multiples of 16
   int dmax;                                // max over definitions of max(min_duration, 1)
+  int debug;                               // timing ablations only (HDP_METRICS_DEBUG): 1 = no stage B, 2 = no stage A
 };
 
 constexpr int kMetWaves = 4;
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_general(
 //     after it either was open (credited above) or lies beyond the season.
 // Season bounds therefore live in SGPRs, the four results are packed 16 seasons per 32-byte
 // sector-aligned store, and the per-run path is branch-free.
-constexpr int kCW = 64;  // 64-day exceedance words per chunk: lane w of a VGPR holds word w
-constexpr int kQB = 8;   // percentiles per stage-A batch
+constexpr int kCW = 32;  // 64-day exceedance words per chunk: lane w of a VGPR holds word w
+constexpr int kQB = 4;   // percentiles per stage-A batch
 
 struct ULane {
   int open, s_open, e_prev;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
     const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
 
   // LDS per wave: thr32 [np_max][n_doy_pad] f32 | bits [np_max][kCW] u64
   unsigned char *wbase = smem + size_t(wave) * md.wave_bytes;
@@ -391,50 +392,105 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
   const float *xc = x + cell * int64_t(md.T);
   const int n_words = (md.T + 63) >> 6;
 
+  // run-skip shortcut: usable for 2 <= min_duration <= 32 (the look-ahead is one 32-day word)
+  const int my_skip = (min_dur >= 2 && min_dur <= 32) ? min_dur : 1;
+  const int skip_max = min(dmax, 32);
+
+  // The chunk's measure values (and their threshold rows) live in registers: all kCW loads of a
+  // chunk are issued back to back right after stage A has consumed the previous ones, so they are
+  // in flight during stage B and HBM latency is off the critical path.
+  const int Tp = n_words * 64;
+  float xr[kCW];
+  uint32_t dr[kCW / 2];  // two 16-bit threshold-row indices per register
+  auto load_chunk = [&](int w0) {
+#pragma unroll
+    for (int w = 0; w < kCW; ++w) {
+      const int t = (w0 + w) * 64 + lane;
+      xr[w] = (t < md.T) ? xc[t] : -INFINITY;  // -inf is never hot
+    }
+#pragma unroll
+    for (int w = 0; w < kCW; w += 2) {
+      const int t = (w0 + w) * 64 + lane;
+      const uint32_t a = (t < Tp) ? md.doy_map[t] : 0u;  // table padded to a multiple of 64
+      const uint32_t b = (t + 64 < Tp) ? md.doy_map[t + 64] : 0u;
+      dr[w / 2] = a | (b << 16);
+    }
+  };
+  load_chunk(0);
+
   for (int w0 = 0; w0 < n_words; w0 += kCW) {
     const int nw = min(kCW, n_words - w0);
+    const bool last_chunk = (w0 + kCW >= n_words);
     // ---- stage A: exceedance words, kQB percentiles at a time; lane w of lo/hi = word w ----------
-    for (int q0 = 0; q0 < np; q0 += kQB) {
-      const int nb = min(kQB, np - q0);
+    for (int q0 = 0; q0 < np && !(md.debug & 2); q0 += kQB) {
       uint32_t lo[kQB], hi[kQB];
+      int roff[kQB];  // LDS row of each percentile of the batch (clamped: the tail repeats the last row)
 #pragma unroll
-      for (int j = 0; j < kQB; ++j) lo[j] = hi[j] = 0;
-#pragma unroll 2
-      for (int w = 0; w < nw; ++w) {
-        const int t = (w0 + w) * 64 + lane;
-        const bool in = t < md.T;
-        const float xv = in ? xc[t] : 0.0f;
-        const int dv = md.doy_map[t];  // table is padded to a multiple of 64
-        const float *tp = thr32 + q0 * md.n_doy_pad + dv;
+      for (int j = 0; j < kQB; ++j) {
+        lo[j] = hi[j] = 0;
+        roff[j] = min(q0 + j, np - 1) * md.n_doy_pad;
+      }
+      // software-pipelined over the 32 words: the threshold reads of word w+1 are in flight while
+      // word w is compared, so LDS latency is paid once per batch, not once per word
+      float tc[kQB], tn[kQB];
+      {
+        const float *tp = thr32 + (dr[0] & 0xffffu);
+#pragma unroll
+        for (int j = 0; j < kQB; ++j) tc[j] = tp[roff[j]];
+      }
+#pragma unroll
+      for (int w = 0; w < kCW; ++w) {
+        if (w + 1 < kCW) {
+          const int dn = ((w + 1) & 1) ? (dr[(w + 1) / 2] >> 16) : (dr[(w + 1) / 2] & 0xffffu);
+          const float *tp = thr32 + dn;
+#pragma unroll
+          for (int j = 0; j < kQB; ++j) tn[j] = tp[roff[j]];
+        }
+        const float xv = xr[w];
 #pragma unroll
         for (int j = 0; j < kQB; ++j) {
-          if (j < nb) {  // wave-uniform
-            const unsigned long long m = __ballot(in && (xv > tp[j * md.n_doy_pad]));
-            // v_cndmask with the (scalar) ballot halves: lane w keeps word w
-            lo[j] = (lane == w) ? (uint32_t)m : lo[j];
-            hi[j] = (lane == w) ? (uint32_t)(m >> 32) : hi[j];
-          }
+          const unsigned long long m = __ballot(xv > tc[j]);
+          // lane w of lo/hi keeps word w.  (No writelane builtin in this clang; the two wait
+          // states are what hipcc itself pads between a VALU SGPR write and v_writelane's read.)
+          asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                       : "+v"(lo[j]), "+v"(hi[j])
+                       : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "i"(w));
         }
+#pragma unroll
+        for (int j = 0; j < kQB; ++j) tc[j] = tn[j];
+        __builtin_amdgcn_sched_barrier(0);  // keep the ballots of different words apart (SGPR pressure)
       }
 #pragma unroll
       for (int j = 0; j < kQB; ++j)
-        if (j < nb) bits64[(q0 + j) * kCW + lane] = ((unsigned long long)hi[j] << 32) | lo[j];
+        if (q0 + j < np && lane < kCW) bits64[(q0 + j) * kCW + lane] = ((unsigned long long)hi[j] << 32) | lo[j];
     }
+    if (w0 + kCW < n_words) load_chunk(w0 + kCW);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- stage B: 32-day half-words, run by run ---------------------------------------------------
-    for (int hw = 0; hw < 2 * nw; ++hw) {
+    for (int hw = 0; hw < 2 * nw && !(md.debug & 1); ++hw) {
       const int t0 = w0 * 64 + hw * 32;
       while (si < Y && sb + dmax <= t0) HDP_FINALIZE(true);  // wave-uniform
       const uint32_t word = valid ? bits32[pi * (2 * kCW) + hw] : 0u;
-      const bool work = st.open ? (word != 0xffffffffu) : (word != 0u);
+      // Runs shorter than min_duration are no-ops while no heatwave is active (they are neither
+      // labelled nor change the state, metric.py:44-58), so in that state the scan jumps straight
+      // to the next run of >= min_duration days: `longs` has bit i set iff days i..i+m-1 are all
+      // hot (looking into the next word; unknown future bits count as hot, which only disables the
+      // shortcut).  While a heatwave is active every run is examined.
+      uint32_t nxt = 0xffffffffu;
+      if (hw + 1 < 2 * nw) nxt = valid ? bits32[pi * (2 * kCW) + hw + 1] : 0u;
+      else if (last_chunk) nxt = 0u;  // beyond the record: not hot
+      uint32_t longs = word;
+      for (int k = 1; k < skip_max; ++k)
+        longs &= (k < my_skip) ? __builtin_amdgcn_alignbit(nxt, word, k) : 0xffffffffu;
+      const bool work = st.open ? (word != 0xffffffffu) : ((st.in_hw ? word : longs) != 0u);
       if (__ballot(work) == 0) continue;
       int pos = 0;
       while (true) {
         if (!st.open) {
-          const uint32_t r = word >> pos;
+          const uint32_t r = (st.in_hw ? word : longs) >> pos;
           if (r == 0) break;
           pos += __builtin_ctz(r);
           st.s_open = t0 + pos;
@@ -617,6 +673,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   md.np_max = std::min(md.P, 63 / md.D + 2);
   md.n_doy_pad = (md.n_doy + 3) & ~3;
   md.dmax = (int)plan->dmax;
+  md.debug = getenv("HDP_METRICS_DEBUG") ? atoi(getenv("HDP_METRICS_DEBUG")) : 0;
   const bool uniform = plan->uniform_seasons && !getenv("HDP_METRICS_GENERAL");
   const size_t seas_bytes = uniform ? 0 : ((size_t(2) * md.Y * sizeof(int2) + 15) & ~size_t(15));
   const size_t thr_bytes = (size_t(md.np_max) * md.n_doy_pad * 4 + 15) & ~size_t(15);
