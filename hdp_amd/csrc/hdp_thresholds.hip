@@ -36,6 +36,7 @@ struct ThrDev {
   const int2 *tgt_top, *tgt_bot;
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
+  int debug;  // timing ablations only (HDP_THR_DEBUG): 1 = no merge, 2 = no sort, 4 = no load
 };
 
 constexpr int kThrThreads = 256;
@@ -77,6 +78,130 @@ __device__ __forceinline__ void bitonic_desc(float (&v)[EPL], int lane) {
   }
 }
 
+// ---- 16-lane-row sorter for S <= 128: four columns per wave, no LDS traffic ------------------
+// Each 16-lane DPP row owns one column; lane l of the row holds elements e = 8*l + i (i = 0..7).
+// Distances 1, 2, 4 are register-to-register, distances 8..64 are lane xor 1, 2, 4 (+ the mirrored
+// first step of each merge), all of which DPP serves inside a row: quad_perm, row_half_mirror,
+// row_mirror and a row_shl/row_shr pair.  Same comparator network as bitonic_desc.
+template <int CTRL, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf,
+                                                     BANK_MASK, false));
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppXor3 = 0x1B;         // quad_perm [3,2,1,0]
+constexpr int kDppHalfMirror = 0x141;  // lane ^ 7 inside each half row
+constexpr int kDppMirror = 0x140;      // lane ^ 15 inside each row
+constexpr int kDppShl4 = 0x104, kDppShr4 = 0x114;
+
+template <int XOR>
+__device__ __forceinline__ float row_xor(float v) {
+  if constexpr (XOR == 1) return dpp_mov<kDppXor1>(v, v);
+  else if constexpr (XOR == 2) return dpp_mov<kDppXor2>(v, v);
+  else if constexpr (XOR == 3) return dpp_mov<kDppXor3>(v, v);
+  else if constexpr (XOR == 7) return dpp_mov<kDppHalfMirror>(v, v);
+  else if constexpr (XOR == 15) return dpp_mov<kDppMirror>(v, v);
+  else {  // XOR == 4: lanes 0-3, 8-11 read lane+4; lanes 4-7, 12-15 read lane-4
+    static_assert(XOR == 4, "unsupported row xor");
+    float t = dpp_mov<kDppShl4, 0x5>(v, v);
+    return dpp_mov<kDppShr4, 0xa>(t, v);
+  }
+}
+
+// max / min through v_med3_f32 (median with +-inf): one instruction each and, unlike fmaxf/fminf,
+// no canonicalising v_max in front (the keys are NaN-free by construction here)
+__device__ __forceinline__ float fmax_nn(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+__device__ __forceinline__ float fmin_nn(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -INFINITY); }
+
+__device__ __forceinline__ void ce_reg(float &a, float &b) {  // larger value to the lower index
+  const float hi = fmax_nn(a, b), lo = fmin_nn(a, b);
+  a = hi;
+  b = lo;
+}
+
+// cross-lane compare-exchange: partner lane = lane ^ XOR, partner register = MIRROR ? 7 - i : i
+// `lim` = +inf on lanes that keep the larger value, -inf on lanes that keep the smaller one:
+// med3(self, other, lim) is then max or min in ONE instruction
+template <int XOR, bool MIRROR>
+__device__ __forceinline__ void ce_cross(float (&v)[8], float lim) {
+  float o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = row_xor<XOR>(v[MIRROR ? 7 - i : i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], o[i], lim);
+}
+
+__device__ __forceinline__ void reg_tail(float (&v)[8]) {  // half-cleaners at distances 4, 2, 1
+  ce_reg(v[0], v[4]); ce_reg(v[1], v[5]); ce_reg(v[2], v[6]); ce_reg(v[3], v[7]);
+  ce_reg(v[0], v[2]); ce_reg(v[1], v[3]); ce_reg(v[4], v[6]); ce_reg(v[5], v[7]);
+  ce_reg(v[0], v[1]); ce_reg(v[2], v[3]); ce_reg(v[4], v[5]); ce_reg(v[6], v[7]);
+}
+
+__device__ __forceinline__ void sort_row128_desc(float (&v)[8], int l /* lane within the row */) {
+  // k = 2, 4, 8: inside the lane
+  ce_reg(v[0], v[1]); ce_reg(v[2], v[3]); ce_reg(v[4], v[5]); ce_reg(v[6], v[7]);
+  ce_reg(v[0], v[3]); ce_reg(v[1], v[2]); ce_reg(v[4], v[7]); ce_reg(v[5], v[6]);
+  ce_reg(v[0], v[1]); ce_reg(v[2], v[3]); ce_reg(v[4], v[5]); ce_reg(v[6], v[7]);
+  ce_reg(v[0], v[7]); ce_reg(v[1], v[6]); ce_reg(v[2], v[5]); ce_reg(v[3], v[4]);
+  ce_reg(v[0], v[2]); ce_reg(v[1], v[3]); ce_reg(v[4], v[6]); ce_reg(v[5], v[7]);
+  ce_reg(v[0], v[1]); ce_reg(v[2], v[3]); ce_reg(v[4], v[5]); ce_reg(v[6], v[7]);
+  const float b0 = (l & 1) ? -INFINITY : INFINITY, b1 = (l & 2) ? -INFINITY : INFINITY;
+  const float b2 = (l & 4) ? -INFINITY : INFINITY, b3 = (l & 8) ? -INFINITY : INFINITY;
+  // k = 16
+  ce_cross<1, true>(v, b0);
+  reg_tail(v);
+  // k = 32
+  ce_cross<3, true>(v, b1);
+  ce_cross<1, false>(v, b0);
+  reg_tail(v);
+  // k = 64
+  ce_cross<7, true>(v, b2);
+  ce_cross<2, false>(v, b1);
+  ce_cross<1, false>(v, b0);
+  reg_tail(v);
+  // k = 128
+  ce_cross<15, true>(v, b3);
+  ce_cross<4, false>(v, b2);
+  ce_cross<2, false>(v, b1);
+  ce_cross<1, false>(v, b0);
+  reg_tail(v);
+}
+
+// Sort up to four LDS columns (lc0 + row, row = lane / 16) at once; S <= 128.
+__device__ __forceinline__ void sort_columns_rows(float *colbuf, int S_pad, int S, int lc0, int ncols,
+                                                  uint32_t *flags, int lane) {
+  const int row = lane >> 4, l = lane & 15;
+  const int lc = lc0 + row;
+  const bool active = lc < ncols;
+  float *col = colbuf + (active ? lc : lc0) * S_pad + 1;
+  float v[8];
+  uint32_t cnt = 0;  // nan << 20 | +inf << 10 | -inf
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = l * 8 + i;
+    float x = (active && e < S) ? col[e] : -INFINITY;
+    const bool real = active && e < S;
+    if (x != x) { cnt += 1u << 20; x = 0.0f; }
+    if (real && x == INFINITY) cnt += 1u << 10;
+    if (real && x == -INFINITY) cnt += 1u;
+    v[i] = x;
+  }
+  sort_row128_desc(v, l);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = l * 8 + i;
+    if (active && e < S) col[e] = v[i];
+  }
+  // row-wide sum of the packed counters (each field < 1024)
+  cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor1, 0xf, 0xf, false);
+  cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor2, 0xf, 0xf, false);
+  cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppHalfMirror, 0xf, 0xf, false);
+  cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppMirror, 0xf, 0xf, false);
+  if (active && l == 0)
+    flags[lc] = ((cnt >> 20) ? 0x80000000u : 0u) | (((cnt >> 10) & 0x3ffu) << 15) | (cnt & 0x3ffu);
+}
+
 // Sort one LDS column (S values at col[0..S)) descending; NaN -> flagged and replaced
 // by 0 (any NaN in a window makes every quantile NaN: numba _collect_percentiles).
 template <int EPL>
@@ -105,9 +230,29 @@ __device__ __forceinline__ void sort_column(float *col, int S, uint32_t *flag_ou
 }
 
 // ---- W-way merge, one lane per day-of-year row -----------------------------------------
+// Heads and their LDS positions live in a lane-private LDS strip laid out [group of 4][row][4], so
+// one step is: all head/position reads issued back to back (NG x ds_read_b128 + NG x ds_read_b64),
+// a compare tree that carries the winner's position along, one dependent read of the winner's
+// next element, two small writes.  NG = ceil(W/4) is a template parameter so the reads are not
+// serialised by a runtime loop (NG = 0: generic fallback).
 template <bool TOP>
+__device__ __forceinline__ bool beats(float a, float b) {  // does a displace b as the current winner?
+  return TOP ? (a >= b) : (a <= b);
+}
+
+template <bool TOP>
+__device__ __forceinline__ void pick(float &bv, uint32_t &bp, float v, uint32_t p) {
+  // NaN (exhausted column / padding) never wins: every comparison with it is false
+  const bool t = beats<TOP>(v, bv);
+  bv = t ? v : bv;
+  bp = t ? p : bp;
+}
+
+// posb holds one 32-bit payload per head: (LDS position << 8) | head slot j, so the winner's
+// position and slot ride through the compare chain in a single register.
+template <bool TOP, int NG>
 __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf, float *hbuf,
-                                          uint16_t *posb, float *rec, const uint16_t *cl,
+                                          uint32_t *posb, float *rec, const uint16_t *cl,
                                           int r /* row within block */) {
   const int RP = pd.RP;
   const int steps = TOP ? pd.steps_top : pd.steps_bot;
@@ -123,37 +268,59 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf,
       h = colbuf[pos];
     }
     hbuf[idx] = h;
-    posb[idx] = (uint16_t)pos;
+    posb[idx] = (uint32_t(pos) << 8) | uint32_t(j);
   }
   const float4 *hb4 = reinterpret_cast<const float4 *>(hbuf);
-  const int ng = pd.Wp >> 2;
+  const uint4 *pb4 = reinterpret_cast<const uint4 *>(posb);
+  const int ng = NG ? NG : (pd.Wp >> 2);
   int k = 0;
+  int next_rank = nt > 0 ? tgt[0].x : -1;  // wave-uniform, refreshed only after an emit
+  const float worst = TOP ? -INFINITY : INFINITY;
   for (int step = 0; step < steps; ++step) {
-    float best = TOP ? -INFINITY : INFINITY;
-    int bj = 0;
-    for (int g = 0; g < ng; ++g) {
-      const float4 h = hb4[g * RP + r];
-      if (TOP) {
-        if (h.x >= best) { best = h.x; bj = 4 * g; }
-        if (h.y >= best) { best = h.y; bj = 4 * g + 1; }
-        if (h.z >= best) { best = h.z; bj = 4 * g + 2; }
-        if (h.w >= best) { best = h.w; bj = 4 * g + 3; }
-      } else {
-        if (h.x <= best) { best = h.x; bj = 4 * g; }
-        if (h.y <= best) { best = h.y; bj = 4 * g + 1; }
-        if (h.z <= best) { best = h.z; bj = 4 * g + 2; }
-        if (h.w <= best) { best = h.w; bj = 4 * g + 3; }
+    float best = worst;
+    uint32_t bp = 0;
+    if constexpr (NG > 0) {
+      float4 h[NG];
+      uint4 q[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) { h[g] = hb4[g * RP + r]; q[g] = pb4[g * RP + r]; }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        pick<TOP>(best, bp, h[g].x, q[g].x);
+        pick<TOP>(best, bp, h[g].y, q[g].y);
+        pick<TOP>(best, bp, h[g].z, q[g].z);
+        pick<TOP>(best, bp, h[g].w, q[g].w);
+      }
+    } else {
+      for (int g = 0; g < ng; ++g) {
+        const float4 h = hb4[g * RP + r];
+        const uint4 q = pb4[g * RP + r];
+        pick<TOP>(best, bp, h.x, q.x);
+        pick<TOP>(best, bp, h.y, q.y);
+        pick<TOP>(best, bp, h.z, q.z);
+        pick<TOP>(best, bp, h.w, q.w);
       }
     }
-    while (k < nt && tgt[k].x == step) {  // wave-uniform
-      rec[tgt[k].y * RP + r] = best;
-      ++k;
+    if (step == next_rank) {  // wave-uniform
+      do {
+        rec[tgt[k].y * RP + r] = best;
+        ++k;
+      } while (k < nt && tgt[k].x == step);
+      next_rank = k < nt ? tgt[k].x : -1;
     }
+    const int bj = int(bp & 0xffu);
     const int idx = ((bj >> 2) * RP + r) * 4 + (bj & 3);
-    const int p = int(posb[idx]) + (TOP ? 1 : -1);
-    posb[idx] = (uint16_t)p;
+    const int p = int(bp >> 8) + (TOP ? 1 : -1);
+    posb[idx] = (uint32_t(p) << 8) | uint32_t(bj);
     hbuf[idx] = colbuf[p];  // runs onto the NaN sentinel when the column is exhausted
   }
+}
+
+template <int NG>
+__device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf, float *hbuf, uint32_t *posb,
+                                           float *rec, const uint16_t *cl, int r) {
+  merge_row<true, NG>(pd, colbuf, hbuf, posb, rec, cl, r);
+  merge_row<false, NG>(pd, colbuf, hbuf, posb, rec, cl, r);
 }
 
 // numba _collect_percentiles_inner: value of quantile p from the recorded order statistics
@@ -203,7 +370,7 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
   off += size_t(pd.Wp) * pd.RP * 4;
   float *rec = reinterpret_cast<float *>(smem + off);
   off += size_t(2 * pd.P) * pd.RP * 4;
-  uint16_t *posb = reinterpret_cast<uint16_t *>(smem + off);
+  uint32_t *posb = reinterpret_cast<uint32_t *>(smem + off);
 
   const int64_t cell = blockIdx.x;
   if (cell >= n_cells) return;
@@ -222,23 +389,35 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
       colbuf[i * pd.S_pad + pd.S + 1] = f32_nan();
     }
 #pragma unroll 4
-    for (int i = tid; i < llen; i += kThrThreads) {
+    for (int i = tid; i < llen && !(pd.debug & 4); i += kThrThreads) {
       const int2 e = list[i];
       colbuf[e.y] = xc[e.x];
     }
     __syncthreads();
 
     // 2. sort every column once
-    for (int lc = wave; lc < ncols; lc += nwaves)
-      sort_column<EPL>(colbuf + lc * pd.S_pad + 1, pd.S, &flags[lc], lane);
+    if (pd.debug & 2) {
+    } else if (pd.S <= 128 && EPL <= 2) {
+      for (int lc0 = wave * 4; lc0 < ncols; lc0 += nwaves * 4)
+        sort_columns_rows(colbuf, pd.S_pad, pd.S, lc0, ncols, flags, lane);
+    } else {
+      for (int lc = wave; lc < ncols; lc += nwaves)
+        sort_column<EPL>(colbuf + lc * pd.S_pad + 1, pd.S, &flags[lc], lane);
+    }
     __syncthreads();
 
     // 3. + 4. merge and interpolate, one lane per row
     if (tid < nrows) {
       const int row = row0 + tid;
       const uint16_t *cl = pd.cols_local + size_t(row) * pd.W;
-      merge_row<true>(pd, colbuf, hbuf, posb, rec, cl, tid);
-      merge_row<false>(pd, colbuf, hbuf, posb, rec, cl, tid);
+      if (!(pd.debug & 1)) {
+        switch (pd.Wp >> 2) {
+          case 1: merge_both<1>(pd, colbuf, hbuf, posb, rec, cl, tid); break;
+          case 2: merge_both<2>(pd, colbuf, hbuf, posb, rec, cl, tid); break;
+          case 4: merge_both<4>(pd, colbuf, hbuf, posb, rec, cl, tid); break;
+          default: merge_both<0>(pd, colbuf, hbuf, posb, rec, cl, tid); break;
+        }
+      }
       bool has_nan = false;
       int n_pos = 0, n_neg = 0;
       for (int j = 0; j < pd.W; ++j) {
@@ -390,6 +569,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.nt_top = plan->nt_top;
   pd.nt_bot = plan->nt_bot;
   pd.n = (int)plan->n;
+  pd.debug = getenv("HDP_THR_DEBUG") ? atoi(getenv("HDP_THR_DEBUG")) : 0;
   switch (plan->epl) {
     case 1: return launch_thr_epl<1>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
     case 2: return launch_thr_epl<2>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
@@ -502,7 +682,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     b += (size_t(ncols) * 4 + 15) & ~size_t(15);
     b += size_t(pl->Wp) * RP * 4;       // heads
     b += size_t(2 * P) * RP * 4;        // recorded order statistics
-    b += size_t(pl->Wp) * RP * 2;       // positions
+    b += size_t(pl->Wp) * RP * 4;       // position | slot payloads
     return b;
   };
   auto cols_of_block = [&](int row0, int rows, std::vector<int> &set) {
@@ -562,7 +742,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   pl->RP = (rows + 63) & ~63;
   pl->ncols_max = cm;
   pl->lds_bytes = lds_for(rows, cm);
-  HDP_REQUIRE(size_t(cm) * spad < 65536, HDP_EUNSUP, "column buffer exceeds 16-bit LDS indexing");
   pl->n_blocks = int((n_doy + rows - 1) / rows);
 
   // per-block tables
