@@ -43,6 +43,18 @@ constexpr int kThrThreads = 256;
 
 __device__ __forceinline__ float f32_nan() { return __int_as_float(0x7fc00000); }
 
+// Order-preserving float <-> int32 key (an involution on the bit pattern): signed integer
+// comparison of keys == float comparison of the NaN-free values, -0 just below +0.  Sorted
+// columns are stored as keys so the merge can use integer max3/min3, and the sentinels around
+// each column (INT_MAX before, INT_MIN after) lose against every real value including +-inf.
+__device__ __forceinline__ int f32_key(float f) {
+  const int b = __float_as_int(f);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float key_f32(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+constexpr int kKeyMax = 0x7fffffff;
+constexpr int kKeyMin = (int)0x80000000;
+
 // ---- column sort: 64*EPL elements held as v[r] = element (r*64 + lane), descending ----
 // One compare-exchange stage: partner = e ^ mask, the element whose `top` bit is clear
 // keeps the larger value.  After full unrolling mask/top are compile-time constants.
@@ -191,7 +203,7 @@ __device__ __forceinline__ void sort_columns_rows(float *colbuf, int S_pad, int 
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int e = l * 8 + i;
-    if (active && e < S) col[e] = v[i];
+    if (active && e < S) col[e] = __int_as_float(f32_key(v[i]));
   }
   // row-wide sum of the packed counters (each field < 1024)
   cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor1, 0xf, 0xf, false);
@@ -224,7 +236,7 @@ __device__ __forceinline__ void sort_column(float *col, int S, uint32_t *flag_ou
 #pragma unroll
   for (int r = 0; r < EPL; ++r) {
     const int e = r * 64 + lane;
-    if (e < S) col[e] = v[r];
+    if (e < S) col[e] = __int_as_float(f32_key(v[r]));
   }
   if (lane == 0) *flag_out = (n_nan ? 0x80000000u : 0u) | (n_pos << 15) | n_neg;
 }
@@ -235,94 +247,6 @@ __device__ __forceinline__ void sort_column(float *col, int S, uint32_t *flag_ou
 // a compare tree that carries the winner's position along, one dependent read of the winner's
 // next element, two small writes.  NG = ceil(W/4) is a template parameter so the reads are not
 // serialised by a runtime loop (NG = 0: generic fallback).
-template <bool TOP>
-__device__ __forceinline__ bool beats(float a, float b) {  // does a displace b as the current winner?
-  return TOP ? (a >= b) : (a <= b);
-}
-
-template <bool TOP>
-__device__ __forceinline__ void pick(float &bv, uint32_t &bp, float v, uint32_t p) {
-  // NaN (exhausted column / padding) never wins: every comparison with it is false
-  const bool t = beats<TOP>(v, bv);
-  bv = t ? v : bv;
-  bp = t ? p : bp;
-}
-
-// posb holds one 32-bit payload per head: (LDS position << 8) | head slot j, so the winner's
-// position and slot ride through the compare chain in a single register.
-template <bool TOP, int NG>
-__device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf, float *hbuf,
-                                          uint32_t *posb, float *rec, const uint16_t *cl,
-                                          int r /* row within block */) {
-  const int RP = pd.RP;
-  const int steps = TOP ? pd.steps_top : pd.steps_bot;
-  const int nt = TOP ? pd.nt_top : pd.nt_bot;
-  const int2 *tgt = TOP ? pd.tgt_top : pd.tgt_bot;
-  if (steps == 0) return;
-  for (int j = 0; j < pd.Wp; ++j) {
-    const int idx = ((j >> 2) * RP + r) * 4 + (j & 3);
-    float h = f32_nan();
-    int pos = 0;
-    if (j < pd.W) {
-      pos = int(cl[j]) * pd.S_pad + (TOP ? 1 : pd.S);
-      h = colbuf[pos];
-    }
-    hbuf[idx] = h;
-    posb[idx] = (uint32_t(pos) << 8) | uint32_t(j);
-  }
-  const float4 *hb4 = reinterpret_cast<const float4 *>(hbuf);
-  const uint4 *pb4 = reinterpret_cast<const uint4 *>(posb);
-  const int ng = NG ? NG : (pd.Wp >> 2);
-  int k = 0;
-  int next_rank = nt > 0 ? tgt[0].x : -1;  // wave-uniform, refreshed only after an emit
-  const float worst = TOP ? -INFINITY : INFINITY;
-  for (int step = 0; step < steps; ++step) {
-    float best = worst;
-    uint32_t bp = 0;
-    if constexpr (NG > 0) {
-      float4 h[NG];
-      uint4 q[NG];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) { h[g] = hb4[g * RP + r]; q[g] = pb4[g * RP + r]; }
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        pick<TOP>(best, bp, h[g].x, q[g].x);
-        pick<TOP>(best, bp, h[g].y, q[g].y);
-        pick<TOP>(best, bp, h[g].z, q[g].z);
-        pick<TOP>(best, bp, h[g].w, q[g].w);
-      }
-    } else {
-      for (int g = 0; g < ng; ++g) {
-        const float4 h = hb4[g * RP + r];
-        const uint4 q = pb4[g * RP + r];
-        pick<TOP>(best, bp, h.x, q.x);
-        pick<TOP>(best, bp, h.y, q.y);
-        pick<TOP>(best, bp, h.z, q.z);
-        pick<TOP>(best, bp, h.w, q.w);
-      }
-    }
-    if (step == next_rank) {  // wave-uniform
-      do {
-        rec[tgt[k].y * RP + r] = best;
-        ++k;
-      } while (k < nt && tgt[k].x == step);
-      next_rank = k < nt ? tgt[k].x : -1;
-    }
-    const int bj = int(bp & 0xffu);
-    const int idx = ((bj >> 2) * RP + r) * 4 + (bj & 3);
-    const int p = int(bp >> 8) + (TOP ? 1 : -1);
-    posb[idx] = (uint32_t(p) << 8) | uint32_t(bj);
-    hbuf[idx] = colbuf[p];  // runs onto the NaN sentinel when the column is exhausted
-  }
-}
-
-template <int NG>
-__device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf, float *hbuf, uint32_t *posb,
-                                           float *rec, const uint16_t *cl, int r) {
-  merge_row<true, NG>(pd, colbuf, hbuf, posb, rec, cl, r);
-  merge_row<false, NG>(pd, colbuf, hbuf, posb, rec, cl, r);
-}
-
 // numba _collect_percentiles_inner: value of quantile p from the recorded order statistics
 __device__ __forceinline__ double finish_quantile(const QuantileParam &qp, float lo, float hi,
                                                   bool has_nan, int n_pos, int n_neg, int n) {
@@ -350,6 +274,154 @@ __device__ __forceinline__ double finish_quantile(const QuantileParam &qp, float
   return val;
 }
 
+template <bool TOP>
+__device__ __forceinline__ int kbest(int a, int b) { return TOP ? max(a, b) : min(a, b); }
+
+// Winner of one group of four heads (keys) with its payload.
+template <bool TOP>
+__device__ __forceinline__ void group_winner(const int4 &h, const uint4 &q, int &m, uint32_t &pay) {
+  m = kbest<TOP>(kbest<TOP>(h.x, h.y), kbest<TOP>(h.z, h.w));
+  pay = q.x;
+  pay = (h.y == m) ? q.y : pay;
+  pay = (h.z == m) ? q.z : pay;
+  pay = (h.w == m) ? q.w : pay;
+}
+
+// what to do when the merge reaches a requested rank (host-built list, sorted by rank)
+enum EmitKind : int { E_TOP_PAIR = 0, E_BOT_PAIR = 1, E_SAME = 2, E_MAX = 3, E_MIN = 4 };
+
+struct RowFlags {  // NaN / infinity census of the row's window (numba's special cases)
+  bool has_nan;
+  int n_pos, n_neg;
+};
+
+// Each requested quantile needs two ADJACENT order statistics, so it is finished the moment the
+// second one appears: `best` is the current merge output, `prev` the one before it.
+template <bool TOP>
+__device__ __forceinline__ void emit_targets(const ThrDev &pd, const int2 *tgt, int nt, int &k, int &next_rank,
+                                             int step, int best, int prev, const RowFlags &rf, bool store,
+                                             double *orow) {
+  do {
+    const int code = tgt[k].y;
+    const int p = code & 0xffff, kind = code >> 16;
+    float lo = key_f32(best), hi = key_f32(best);
+    if (kind == E_TOP_PAIR) hi = key_f32(prev);
+    if (kind == E_BOT_PAIR) lo = key_f32(prev);
+    if (store) orow[p] = finish_quantile(pd.qp[p], lo, hi, rf.has_nan, rf.n_pos, rf.n_neg, pd.n);
+    ++k;
+  } while (k < nt && tgt[k].x == step);
+  next_rank = k < nt ? tgt[k].x : -1;
+}
+
+// ---- W-way merge, one lane per day-of-year row ------------------------------------------------
+// Heads (keys) and payloads ((LDS position << 8) | head slot) live in a lane-private LDS strip
+// [group of 4][row][4].  The winner of every group is cached in registers; a step
+//   1. takes the best cached group winner (NG-1 max + selects),
+//   2. issues, together, the read of the winner column's next key and of the winner's group,
+//   3. patches the group in registers, recomputes that one group winner, writes the new head back.
+// One LDS round trip per step, no full rescan of the W heads.  NG = ceil(W/4) is a template
+// parameter (NG = 0: generic rescan loop for very wide windows).
+template <bool TOP, int NG>
+__device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_f, float *hbuf_f,
+                                          uint32_t *posb, const uint16_t *cl, int r /* row within block */,
+                                          const RowFlags &rf, bool store, double *orow) {
+  const int *colbuf = reinterpret_cast<const int *>(colbuf_f);
+  int *hbuf = reinterpret_cast<int *>(hbuf_f);
+  const int RP = pd.RP;
+  const int steps = TOP ? pd.steps_top : pd.steps_bot;
+  const int nt = TOP ? pd.nt_top : pd.nt_bot;
+  const int2 *tgt = TOP ? pd.tgt_top : pd.tgt_bot;
+  if (steps == 0) return;
+  const int worst = TOP ? kKeyMin : kKeyMax;
+  for (int j = 0; j < pd.Wp; ++j) {
+    const int idx = ((j >> 2) * RP + r) * 4 + (j & 3);
+    int h = worst;
+    int pos = 0;
+    if (j < pd.W) {
+      pos = int(cl[j]) * pd.S_pad + (TOP ? 1 : pd.S);
+      h = colbuf[pos];
+    }
+    hbuf[idx] = h;
+    posb[idx] = (uint32_t(pos) << 8) | uint32_t(j);
+  }
+  int4 *hb4 = reinterpret_cast<int4 *>(hbuf);
+  uint4 *pb4 = reinterpret_cast<uint4 *>(posb);
+  int k = 0;
+  int next_rank = nt > 0 ? __builtin_amdgcn_readfirstlane(tgt[0].x) : -1;
+  int prev = worst;
+  if constexpr (NG > 0) {
+    int m[NG];
+    uint32_t pay[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) group_winner<TOP>(hb4[g * RP + r], pb4[g * RP + r], m[g], pay[g]);
+    for (int step = 0; step < steps; ++step) {
+      int best = m[0];
+#pragma unroll
+      for (int g = 1; g < NG; ++g) best = kbest<TOP>(best, m[g]);
+      uint32_t bp = pay[0];
+#pragma unroll
+      for (int g = 1; g < NG; ++g) bp = (m[g] == best) ? pay[g] : bp;
+      if (step == next_rank) {  // wave-uniform
+        emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, best, prev, rf, store, orow);
+        next_rank = __builtin_amdgcn_readfirstlane(next_rank);
+      }
+      prev = best;
+      const int bj = int(bp & 0xffu);
+      const int gw = bj >> 2, jw = bj & 3;
+      const int p = int(bp >> 8) + (TOP ? 1 : -1);
+      const int gidx = gw * RP + r;
+      // three independent reads: next key of the winning column, the winner's group
+      const int nk = colbuf[p];  // the column's sentinel once it is exhausted
+      int4 h = hb4[gidx];
+      uint4 q = pb4[gidx];
+      const uint32_t np = (uint32_t(p) << 8) | uint32_t(bj);
+      h.x = (jw == 0) ? nk : h.x; q.x = (jw == 0) ? np : q.x;
+      h.y = (jw == 1) ? nk : h.y; q.y = (jw == 1) ? np : q.y;
+      h.z = (jw == 2) ? nk : h.z; q.z = (jw == 2) ? np : q.z;
+      h.w = (jw == 3) ? nk : h.w; q.w = (jw == 3) ? np : q.w;
+      hbuf[gidx * 4 + jw] = nk;
+      posb[gidx * 4 + jw] = np;
+      int mg;
+      uint32_t pg;
+      group_winner<TOP>(h, q, mg, pg);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        m[g] = (gw == g) ? mg : m[g];
+        pay[g] = (gw == g) ? pg : pay[g];
+      }
+    }
+  } else {
+    const int ng = pd.Wp >> 2;
+    for (int step = 0; step < steps; ++step) {
+      int best = worst;
+      uint32_t bp = 0;
+      for (int g = 0; g < ng; ++g) {
+        int m;
+        uint32_t pay;
+        group_winner<TOP>(hb4[g * RP + r], pb4[g * RP + r], m, pay);
+        const bool t = TOP ? (m >= best) : (m <= best);
+        best = t ? m : best;
+        bp = t ? pay : bp;
+      }
+      if (step == next_rank) emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, best, prev, rf, store, orow);
+      prev = best;
+      const int bj = int(bp & 0xffu);
+      const int idx = ((bj >> 2) * RP + r) * 4 + (bj & 3);
+      const int p = int(bp >> 8) + (TOP ? 1 : -1);
+      posb[idx] = (uint32_t(p) << 8) | uint32_t(bj);
+      hbuf[idx] = colbuf[p];
+    }
+  }
+}
+
+template <int NG>
+__device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf, float *hbuf, uint32_t *posb,
+                                           const uint16_t *cl, int r, const RowFlags &rf, bool store,
+                                           double *orow) {
+  merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+  merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+}
+
 template <int EPL>
 __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, const float *__restrict__ x,
                                                                  int64_t n_cells,
@@ -368,8 +440,6 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
   off += (size_t(pd.ncols_max) * 4 + 15) & ~size_t(15);
   float *hbuf = reinterpret_cast<float *>(smem + off);
   off += size_t(pd.Wp) * pd.RP * 4;
-  float *rec = reinterpret_cast<float *>(smem + off);
-  off += size_t(2 * pd.P) * pd.RP * 4;
   uint32_t *posb = reinterpret_cast<uint32_t *>(smem + off);
 
   const int64_t cell = blockIdx.x;
@@ -385,10 +455,10 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
 
     // 1. sentinels + load
     for (int i = tid; i < ncols; i += kThrThreads) {
-      colbuf[i * pd.S_pad] = f32_nan();
-      colbuf[i * pd.S_pad + pd.S + 1] = f32_nan();
+      colbuf[i * pd.S_pad] = __int_as_float(kKeyMax);          // below every ascending walk
+      colbuf[i * pd.S_pad + pd.S + 1] = __int_as_float(kKeyMin);  // below every descending walk
     }
-#pragma unroll 4
+#pragma unroll 8
     for (int i = tid; i < llen && !(pd.debug & 4); i += kThrThreads) {
       const int2 e = list[i];
       colbuf[e.y] = xc[e.x];
@@ -406,31 +476,26 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
     }
     __syncthreads();
 
-    // 3. + 4. merge and interpolate, one lane per row
+    // 3. + 4. merge and interpolate, one lane per row; every quantile is stored as soon as its
+    //         second order statistic comes out of the merge
     if (tid < nrows) {
       const int row = row0 + tid;
       const uint16_t *cl = pd.cols_local + size_t(row) * pd.W;
-      if (!(pd.debug & 1)) {
-        switch (pd.Wp >> 2) {
-          case 1: merge_both<1>(pd, colbuf, hbuf, posb, rec, cl, tid); break;
-          case 2: merge_both<2>(pd, colbuf, hbuf, posb, rec, cl, tid); break;
-          case 4: merge_both<4>(pd, colbuf, hbuf, posb, rec, cl, tid); break;
-          default: merge_both<0>(pd, colbuf, hbuf, posb, rec, cl, tid); break;
-        }
-      }
-      bool has_nan = false;
-      int n_pos = 0, n_neg = 0;
+      RowFlags rf{false, 0, 0};
       for (int j = 0; j < pd.W; ++j) {
         const uint32_t f = flags[cl[j]];
-        has_nan |= (f >> 31) != 0;
-        n_pos += (f >> 15) & 0x7fff;
-        n_neg += f & 0x7fff;
+        rf.has_nan |= (f >> 31) != 0;
+        rf.n_pos += (f >> 15) & 0x7fff;
+        rf.n_neg += f & 0x7fff;
       }
-      double *o = out + (cell * pd.n_doy + row) * int64_t(pd.P);
-      for (int p = 0; p < pd.P; ++p) {
-        const float lo = rec[(2 * p) * pd.RP + tid];
-        const float hi = rec[(2 * p + 1) * pd.RP + tid];
-        o[p] = finish_quantile(pd.qp[p], lo, hi, has_nan, n_pos, n_neg, pd.n);
+      double *orow = out + (cell * pd.n_doy + row) * int64_t(pd.P);
+      if (!(pd.debug & 1)) {
+        switch (pd.Wp >> 2) {
+          case 1: merge_both<1>(pd, colbuf, hbuf, posb, cl, tid, rf, true, orow); break;
+          case 2: merge_both<2>(pd, colbuf, hbuf, posb, cl, tid, rf, true, orow); break;
+          case 4: merge_both<4>(pd, colbuf, hbuf, posb, cl, tid, rf, true, orow); break;
+          default: merge_both<0>(pd, colbuf, hbuf, posb, cl, tid, rf, true, orow); break;
+        }
       }
     }
     __syncthreads();
@@ -620,7 +685,8 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   HDP_REQUIRE(T < (int64_t(1) << 31), HDP_EUNSUP, "T too large");
   HDP_REQUIRE(n_doy < 65536, HDP_EUNSUP, "n_doy too large");
   HDP_REQUIRE(S <= 2048, HDP_EUNSUP, "S=%lld samples per day-of-year exceeds 2048", (long long)S);
-  HDP_REQUIRE(P <= 4096, HDP_EUNSUP, "too many quantiles");
+  HDP_REQUIRE(P <= 65535, HDP_EUNSUP, "too many quantiles");
+  HDP_REQUIRE(W <= 252, HDP_EUNSUP, "window of %lld day-of-year columns exceeds 252", (long long)W);
   for (int64_t i = 0; i < n_doy * S; ++i)
     HDP_REQUIRE(time_index[i] >= -T && time_index[i] < T, HDP_EINVAL,
                 "time_index[%lld]=%lld outside [-T, T)", (long long)i, (long long)time_index[i]);
@@ -641,7 +707,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
 
   // quantile parameters and merge targets
   std::vector<hdp::QuantileParam> qp(P);
-  struct Tgt { int rank, slot; };
+  struct Tgt { int rank, slot; };  // slot = quantile index | EmitKind << 16
   std::vector<Tgt> top, bot;
   const int64_t n = pl->n;
   for (int64_t p = 0; p < P; ++p) {
@@ -652,19 +718,19 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
       return set_error(HDP_EQUANT, "Quantiles must be in the range [0, 1]");
     }
     if (qp[p].mode == hdp::Q_MAX) {
-      top.push_back({0, int(2 * p + 1)});
+      top.push_back({0, int(p) | (hdp::E_MAX << 16)});
     } else if (qp[p].mode == hdp::Q_MIN) {
-      bot.push_back({0, int(2 * p)});
+      bot.push_back({0, int(p) | (hdp::E_MIN << 16)});
     } else {
+      // lower = ascending[klo], upper = ascending[khi], khi = klo + 1 (or klo at the clamp): the
+      // quantile is emitted at the later of the two ranks in merge order
       const int64_t from_top = (n - 1 - klo) + 1;  // merge steps needed coming from the top
       const int64_t from_bot = khi + 1;
-      if (from_top <= from_bot) {
-        top.push_back({int(n - 1 - klo), int(2 * p)});
-        top.push_back({int(n - 1 - khi), int(2 * p + 1)});
-      } else {
-        bot.push_back({int(klo), int(2 * p)});
-        bot.push_back({int(khi), int(2 * p + 1)});
-      }
+      const int same = (khi == klo) ? 1 : 0;
+      if (from_top <= from_bot)
+        top.push_back({int(n - 1 - klo), int(p) | ((same ? hdp::E_SAME : hdp::E_TOP_PAIR) << 16)});
+      else
+        bot.push_back({int(khi), int(p) | ((same ? hdp::E_SAME : hdp::E_BOT_PAIR) << 16)});
     }
   }
   auto by_rank = [](const Tgt &a, const Tgt &b) { return a.rank < b.rank; };
@@ -681,7 +747,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     size_t b = (size_t(ncols) * spad * 4 + 15) & ~size_t(15);
     b += (size_t(ncols) * 4 + 15) & ~size_t(15);
     b += size_t(pl->Wp) * RP * 4;       // heads
-    b += size_t(2 * P) * RP * 4;        // recorded order statistics
     b += size_t(pl->Wp) * RP * 4;       // position | slot payloads
     return b;
   };
