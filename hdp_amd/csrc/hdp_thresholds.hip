@@ -458,10 +458,22 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
       colbuf[i * pd.S_pad] = __int_as_float(kKeyMax);          // below every ascending walk
       colbuf[i * pd.S_pad + pd.S + 1] = __int_as_float(kKeyMin);  // below every descending walk
     }
-#pragma unroll 8
-    for (int i = tid; i < llen && !(pd.debug & 4); i += kThrThreads) {
-      const int2 e = list[i];
-      colbuf[e.y] = xc[e.x];
+    // batches of kLoadBatch independent (list entry -> sample -> LDS) chains per thread: all list
+    // reads of a batch are issued before the first sample read, all sample reads before the first
+    // LDS write, so a thread keeps kLoadBatch HBM requests in flight instead of one
+    if (!(pd.debug & 4)) {
+      constexpr int kLoadBatch = 8;
+      for (int base = tid; base < llen; base += kThrThreads * kLoadBatch) {
+        int2 e[kLoadBatch];
+        float v[kLoadBatch];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) e[u] = list[min(base + u * kThrThreads, llen - 1)];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) v[u] = xc[e[u].x];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u)
+          if (base + u * kThrThreads < llen) colbuf[e[u].y] = v[u];
+      }
     }
     __syncthreads();
 
