@@ -102,6 +102,7 @@ struct hdp_metrics_plan {
   hdp::DevBuf doy_map;   // uint16 [T rounded up to 64]
   hdp::DevBuf defs;      // int32 [D][3]
   hdp::DevBuf seasons;   // int2 [2][Y]  (north, south)
+  mutable hdp::DevBuf bits_scratch;  // split path: exceedance words of one batch of series
 };
 
 namespace hdp {

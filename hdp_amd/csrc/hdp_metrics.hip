@@ -35,6 +35,9 @@ struct MetDev {
   int seas_bytes, thr_bytes, wave_bytes;  // LDS carve, all multiples of 16
   int dmax;                                // max over definitions of max(min_duration, 1)
   int debug;                               // timing ablations only (HDP_METRICS_DEBUG): 1 = no stage B, 2 = no stage A
+  unsigned long long *bits_g;              // split path: exceedance words [cell][P][words_pad] in HBM
+  int words_pad;                           // 64-day words per (cell, percentile) row, multiple of kCW
+  long long out_cells, cell_off;           // series count of the whole output / offset of this launch's first series
 };
 
 constexpr int kMetWaves = 4;
@@ -161,8 +164,8 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_general(
   const int min_dur = md.defs[my_d * 3 + 0];
   const int max_break = md.defs[my_d * 3 + 1];
   const int max_subs = md.defs[my_d * 3 + 2];
-  const int64_t row = ((int64_t(my_p) * md.D + my_d) * n_cells + cell) * md.Ypitch;
-  const int64_t plane = int64_t(md.P) * md.D * n_cells * md.Ypitch;
+  const int64_t row = ((int64_t(my_p) * md.D + my_d) * md.out_cells + md.cell_off + cell) * md.Ypitch;
+  const int64_t plane = int64_t(md.P) * md.D * md.out_cells * md.Ypitch;
   int16_t *out_f = out + row;
   int16_t *out_n = out_f + plane;
   int16_t *out_d = out_n + plane;
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_general(
 // sector-aligned store, and the per-run path is branch-free.
 constexpr int kCW = 32;  // 64-day exceedance words per chunk: lane w of a VGPR holds word w
 constexpr int kQB = 4;   // percentiles per stage-A batch
+constexpr int kRow = kCW + 1;  // u64 pitch of one percentile's words in LDS (odd: rows on different banks)
 
 struct ULane {
   int open, s_open, e_prev;
@@ -288,6 +292,88 @@ __device__ __forceinline__ void store32(int16_t *dst, const uint32_t (&a)[8]) {
   p[1] = make_uint4(a[4], a[5], a[6], a[7]);
 }
 
+// ---- split path, kernel 1: exceedance words of every percentile -> HBM -------------------------
+// One 256-thread workgroup per series: the thresholds (f32 rounded toward -inf) are staged in LDS
+// once per series and shared by the four waves, each of which converts every fourth 2048-day chunk.
+// With only ~15 KB of LDS per workgroup the CU holds ~40 waves, so this streaming kernel hides HBM
+// latency by occupancy; the state-machine kernel that follows then needs no thresholds at all.
+__global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__restrict__ x,
+                                                     const double *__restrict__ thr, int64_t n_thr_cells,
+                                                     int64_t n_cells) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *thr32 = reinterpret_cast<float *>(smem);  // [P][n_doy_pad]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t cell = blockIdx.x;
+  {
+    const double *tc = thr + (cell % n_thr_cells) * int64_t(md.n_doy) * md.P;
+    for (int doy = threadIdx.x; doy < md.n_doy; doy += 256)
+      for (int q = 0; q < md.P; ++q)
+        thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(doy) * md.P + q]);
+  }
+  __syncthreads();
+  const float *xc = x + cell * int64_t(md.T);
+  const int n_words = (md.T + 63) >> 6;
+  const int Tp = n_words * 64;
+  unsigned long long *brow = md.bits_g + cell * md.P * int64_t(md.words_pad);
+  for (int w0 = wave * kCW; w0 < n_words; w0 += 4 * kCW) {
+    float xr[kCW];
+    uint32_t dr[kCW / 2];
+#pragma unroll
+    for (int w = 0; w < kCW; ++w) {
+      const int t = (w0 + w) * 64 + lane;
+      xr[w] = (t < md.T) ? xc[t] : -INFINITY;
+    }
+#pragma unroll
+    for (int w = 0; w < kCW; w += 2) {
+      const int t = (w0 + w) * 64 + lane;
+      const uint32_t a = (t < Tp) ? md.doy_map[t] : 0u;
+      const uint32_t b = (t + 64 < Tp) ? md.doy_map[t + 64] : 0u;
+      dr[w / 2] = a | (b << 16);
+    }
+    for (int q0 = 0; q0 < md.P; q0 += kQB) {
+      uint32_t lo[kQB], hi[kQB];
+      int roff[kQB];
+#pragma unroll
+      for (int j = 0; j < kQB; ++j) {
+        lo[j] = hi[j] = 0;
+        roff[j] = min(q0 + j, md.P - 1) * md.n_doy_pad;
+      }
+      float tc[kQB], tn[kQB];
+      {
+        const float *tp = thr32 + (dr[0] & 0xffffu);
+#pragma unroll
+        for (int j = 0; j < kQB; ++j) tc[j] = tp[roff[j]];
+      }
+#pragma unroll
+      for (int w = 0; w < kCW; ++w) {
+        if (w + 1 < kCW) {
+          const int dn = ((w + 1) & 1) ? (dr[(w + 1) / 2] >> 16) : (dr[(w + 1) / 2] & 0xffffu);
+          const float *tp = thr32 + dn;
+#pragma unroll
+          for (int j = 0; j < kQB; ++j) tn[j] = tp[roff[j]];
+        }
+        const float xv = xr[w];
+#pragma unroll
+        for (int j = 0; j < kQB; ++j) {
+          const unsigned long long m = __ballot(xv > tc[j]);
+          asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                       : "+v"(lo[j]), "+v"(hi[j])
+                       : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "i"(w));
+        }
+#pragma unroll
+        for (int j = 0; j < kQB; ++j) tc[j] = tn[j];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < kQB; ++j)
+        if (q0 + j < md.P && lane < kCW)
+          brow[int64_t(q0 + j) * md.words_pad + w0 + lane] = ((unsigned long long)hi[j] << 32) | lo[j];
+    }
+  }
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
     MetDev md, const float *__restrict__ x, const double *__restrict__ thr, int64_t n_thr_cells,
     const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
@@ -317,7 +403,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
   const int my_d = valid ? combo % md.D : 0;
   const int pi = my_p - p_lo;
 
-  {  // thresholds of this series -> LDS as f32 rounded toward -inf
+  if constexpr (!SPLIT) {  // thresholds of this series -> LDS as f32 rounded toward -inf
     const double *tc = thr + (cell % n_thr_cells) * int64_t(md.n_doy) * md.P;
     for (int d0 = 0; d0 < md.n_doy; d0 += 64) {
       const int doy = d0 + lane;
@@ -342,8 +428,8 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
   const int max_subs = md.defs[my_d * 3 + 2];
   const int dmax = md.dmax;
   const int Ypitch_unused = md.Ypitch; (void)Ypitch_unused;
-  const int64_t row = ((int64_t(my_p) * md.D + my_d) * n_cells + cell) * md.Ypitch;
-  const int64_t plane = int64_t(md.P) * md.D * n_cells * md.Ypitch;
+  const int64_t row = ((int64_t(my_p) * md.D + my_d) * md.out_cells + md.cell_off + cell) * md.Ypitch;
+  const int64_t plane = int64_t(md.P) * md.D * md.out_cells * md.Ypitch;
   int16_t *orow = out + row;
 
   ULane st;
@@ -400,6 +486,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
   // chunk are issued back to back right after stage A has consumed the previous ones, so they are
   // in flight during stage B and HBM latency is off the critical path.
   const int Tp = n_words * 64;
+  const unsigned long long *brow = SPLIT ? md.bits_g + (cell * md.P + p_lo) * int64_t(md.words_pad) : nullptr;
   float xr[kCW];
   uint32_t dr[kCW / 2];  // two 16-bit threshold-row indices per register
   auto load_chunk = [&](int w0) {
@@ -416,13 +503,18 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
       dr[w / 2] = a | (b << 16);
     }
   };
-  load_chunk(0);
+  if constexpr (!SPLIT) load_chunk(0);
 
   for (int w0 = 0; w0 < n_words; w0 += kCW) {
     const int nw = min(kCW, n_words - w0);
     const bool last_chunk = (w0 + kCW >= n_words);
+    if constexpr (SPLIT) {
+      // exceedance words were produced by exceed_kernel: two percentile rows per 512-byte load
+      for (int q = (lane >> 5); q < np; q += 2)
+        bits64[q * kRow + (lane & 31)] = brow[int64_t(q) * md.words_pad + w0 + (lane & 31)];
+    }
     // ---- stage A: exceedance words, kQB percentiles at a time; lane w of lo/hi = word w ----------
-    for (int q0 = 0; q0 < np && !(md.debug & 2); q0 += kQB) {
+    for (int q0 = 0; q0 < np && !SPLIT && !(md.debug & 2); q0 += kQB) {
       uint32_t lo[kQB], hi[kQB];
       int roff[kQB];  // LDS row of each percentile of the batch (clamped: the tail repeats the last row)
 #pragma unroll
@@ -462,9 +554,11 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
       }
 #pragma unroll
       for (int j = 0; j < kQB; ++j)
-        if (q0 + j < np && lane < kCW) bits64[(q0 + j) * kCW + lane] = ((unsigned long long)hi[j] << 32) | lo[j];
+        if (q0 + j < np && lane < kCW) bits64[(q0 + j) * kRow + lane] = ((unsigned long long)hi[j] << 32) | lo[j];
     }
-    if (w0 + kCW < n_words) load_chunk(w0 + kCW);
+    if constexpr (!SPLIT) {
+      if (w0 + kCW < n_words) load_chunk(w0 + kCW);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -473,14 +567,14 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
     for (int hw = 0; hw < 2 * nw && !(md.debug & 1); ++hw) {
       const int t0 = w0 * 64 + hw * 32;
       while (si < Y && sb + dmax <= t0) HDP_FINALIZE(true);  // wave-uniform
-      const uint32_t word = valid ? bits32[pi * (2 * kCW) + hw] : 0u;
+      const uint32_t word = valid ? bits32[pi * (2 * kRow) + hw] : 0u;
       // Runs shorter than min_duration are no-ops while no heatwave is active (they are neither
       // labelled nor change the state, metric.py:44-58), so in that state the scan jumps straight
       // to the next run of >= min_duration days: `longs` has bit i set iff days i..i+m-1 are all
       // hot (looking into the next word; unknown future bits count as hot, which only disables the
       // shortcut).  While a heatwave is active every run is examined.
       uint32_t nxt = 0xffffffffu;
-      if (hw + 1 < 2 * nw) nxt = valid ? bits32[pi * (2 * kCW) + hw + 1] : 0u;
+      if (hw + 1 < 2 * nw) nxt = valid ? bits32[pi * (2 * kRow) + hw + 1] : 0u;
       else if (last_chunk) nxt = 0u;  // beyond the record: not hot
       uint32_t longs = word;
       for (int k = 1; k < skip_max; ++k)
@@ -674,25 +768,76 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   md.n_doy_pad = (md.n_doy + 3) & ~3;
   md.dmax = (int)plan->dmax;
   md.debug = getenv("HDP_METRICS_DEBUG") ? atoi(getenv("HDP_METRICS_DEBUG")) : 0;
+  md.bits_g = nullptr;
+  md.out_cells = n_cells;
+  md.cell_off = 0;
+  md.words_pad = ((((md.T + 63) >> 6) + kCW - 1) / kCW) * kCW;
   const bool uniform = plan->uniform_seasons && !getenv("HDP_METRICS_GENERAL");
+  const bool split = uniform && !getenv("HDP_METRICS_FUSED");
   const size_t seas_bytes = uniform ? 0 : ((size_t(2) * md.Y * sizeof(int2) + 15) & ~size_t(15));
-  const size_t thr_bytes = (size_t(md.np_max) * md.n_doy_pad * 4 + 15) & ~size_t(15);
-  const size_t per_wave = thr_bytes + size_t(md.np_max) * (uniform ? kCW : kChunkWords) * 8;
+  const size_t thr_bytes = split ? 0 : ((size_t(md.np_max) * md.n_doy_pad * 4 + 15) & ~size_t(15));
+  const size_t per_wave = thr_bytes + size_t(md.np_max) * (uniform ? kRow : kChunkWords) * 8;
   const size_t lds = seas_bytes + kMetWaves * per_wave;
   md.seas_bytes = (int)seas_bytes;
   md.thr_bytes = (int)thr_bytes;
   md.wave_bytes = (int)per_wave;
   HDP_REQUIRE(lds <= kLdsPerCU - 1024, HDP_EUNSUP,
               "metrics kernel needs %zu bytes of LDS (P=%d, n_doy=%d, Y=%d)", lds, md.P, md.n_doy, md.Y);
-  const int64_t tasks = n_cells * md.n_groups;
-  const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
-  HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
-  auto kern = uniform ? metrics_kernel_uniform : metrics_kernel_general;
-  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+  if (!split) {
+    const int64_t tasks = n_cells * md.n_groups;
+    const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
+    HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
+    auto kern = uniform ? metrics_kernel_uniform<false> : metrics_kernel_general;
+    HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, md, x_dev,
+                       thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev);
+    HDP_HIP_TRY(hipGetLastError());
+    return HDP_OK;
+  }
+  // split path: exceedance words through an HBM scratch, in batches of series
+  const size_t row_bytes = size_t(md.P) * md.words_pad * 8;
+  int64_t batch = std::max<int64_t>(1, (int64_t(4) << 30) / (int64_t)row_bytes);
+  if (const char *env = getenv("HDP_METRICS_BATCH")) batch = std::max<int64_t>(1, atoll(env));
+  if (n_thr_cells != n_cells && batch < n_cells)  // members share thresholds: keep c % n_thr_cells intact
+    batch = std::max<int64_t>(n_thr_cells, batch / n_thr_cells * n_thr_cells);
+  batch = std::min<int64_t>(batch, n_cells);
+  if (plan->bits_scratch.bytes < size_t(batch) * row_bytes) {
+    HDP_HIP_TRY(hipStreamSynchronize(stream));  // the old scratch may still be in use
+    hipError_t e = plan->bits_scratch.alloc(size_t(batch) * row_bytes);
+    if (e != hipSuccess)
+      return set_error(HDP_ENOMEM, "allocating %zu bytes of exceedance scratch failed: %s",
+                       size_t(batch) * row_bytes, hipGetErrorString(e));
+  }
+  md.bits_g = plan->bits_scratch.as<unsigned long long>();
+  const size_t lds_a = (size_t(md.P) * md.n_doy_pad * 4 + 15) & ~size_t(15);
+  HDP_REQUIRE(lds_a <= kLdsPerCU - 1024, HDP_EUNSUP, "too many percentiles for the exceedance kernel");
+  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(exceed_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+  auto kern_b = metrics_kernel_uniform<true>;
+  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_b),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, md, x_dev,
-                     thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev);
-  HDP_HIP_TRY(hipGetLastError());
+  for (int64_t c0 = 0; c0 < n_cells; c0 += batch) {
+    const int64_t nc = std::min(batch, n_cells - c0);
+    // NOTE: series c of the batch is series c0 + c of the call: pointers are offset, the
+    // (c % n_thr_cells) threshold mapping is kept by offsetting the threshold base when it is 1:1
+    const bool one_to_one = (n_thr_cells == n_cells);
+    HDP_REQUIRE(one_to_one || c0 % n_thr_cells == 0 || batch >= n_cells, HDP_EUNSUP,
+                "shared thresholds need batches aligned to the number of threshold cells");
+    const double *thr_b = one_to_one ? thr_dev + c0 * int64_t(md.n_doy) * md.P : thr_dev;
+    const int64_t ntc_b = one_to_one ? nc : n_thr_cells;
+    hipLaunchKernelGGL(exceed_kernel, dim3((unsigned)nc), dim3(256), lds_a, stream, md, x_dev + c0 * int64_t(md.T),
+                       thr_b, ntc_b, nc);
+    HDP_HIP_TRY(hipGetLastError());
+    // the state-machine kernel indexes the output with the FULL series count and this batch's offset
+    MetDev mb = md;
+    mb.cell_off = c0;
+    const int64_t tasks = nc * md.n_groups;
+    const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
+    hipLaunchKernelGGL(kern_b, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, mb, x_dev, thr_b, ntc_b,
+                       is_south_dev + c0, nc, out_dev);
+    HDP_HIP_TRY(hipGetLastError());
+  }
   return HDP_OK;
 }
 

@@ -345,3 +345,14 @@ def test_metrics_long_min_duration_and_record_end():
     got = core.compute_heatwave_metrics(x, thr, doy_map, defs, north, south, is_south)
     want = orc.compute_metrics_cells(x, thr, doy_map, defs, north, south, is_south)
     assert np.array_equal(got.astype(np.int64), want)
+
+
+def test_metrics_split_path_in_small_batches(monkeypatch):
+    """Exceedance-scratch path forced into several batches (ragged last one), and the fused kernel."""
+    case = _random_metrics_case(123, 5, 11, 4, [[3, 0, 0], [3, 1, 1], [4, 2, 2]], trend=1.0)
+    want = orc.compute_metrics_cells(*case)
+    monkeypatch.setenv("HDP_METRICS_BATCH", "4")
+    assert np.array_equal(core.compute_heatwave_metrics(*case).astype(np.int64), want)
+    monkeypatch.delenv("HDP_METRICS_BATCH")
+    monkeypatch.setenv("HDP_METRICS_FUSED", "1")
+    assert np.array_equal(core.compute_heatwave_metrics(*case).astype(np.int64), want)
