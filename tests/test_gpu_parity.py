@@ -356,3 +356,53 @@ def test_metrics_split_path_in_small_batches(monkeypatch):
     monkeypatch.delenv("HDP_METRICS_BATCH")
     monkeypatch.setenv("HDP_METRICS_FUSED", "1")
     assert np.array_equal(core.compute_heatwave_metrics(*case).astype(np.int64), want)
+
+
+def test_c2_full_size_cross_kernel_properties(monkeypatch):
+    """BASELINE config 2 at FULL size (3650 d x 180 x 360 = 64800 cells, 10 percentiles x 6
+    definitions), too big for the Python oracle: size-independent properties instead --
+      * the three independently written metrics kernels (split, fused, general) agree bit for bit;
+      * the plan-based threshold kernel agrees bit for bit with the literal-table kernel on a sample;
+      * thresholds are non-decreasing in the percentile; HWF >= HWD >= HWA >= 0; HWN <= HWF;
+        HWA == HWF // HWN;  all-zero where HWN == 0;
+      * a sample of cells matches the C oracle exactly."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(2024)
+    dates = orc.noleap_date_range("2001-01-01", "2010-12-31")
+    T, n_lat, n_lon = dates.size, 180, 360
+    n = n_lat * n_lon
+    lat = np.repeat(np.linspace(-90, 90, n_lat), n_lon)
+    t = np.arange(T, dtype=np.float32)
+    season = (20 + 8 * np.sin(2 * np.pi * (t - 110) / 365)).astype(np.float32)
+    base = season[None, :] - (10 * np.abs(lat) / 90).astype(np.float32)[:, None] \
+        + rng.normal(0, 2.0, size=(n, T)).astype(np.float32)
+    meas = base + np.float32(0.6) + (t / np.float32(36500.0))[None, :] \
+        + rng.normal(0, 1.0, size=(n, T)).astype(np.float32)
+    q = np.arange(0.9, 1, 0.01)
+    defs = [[3, 0, 0], [3, 1, 1], [4, 0, 0], [4, 1, 1], [5, 0, 0], [5, 1, 1]]
+    ti, cols = cal.window_columns(dates, 7)
+    thr = core.compute_percentiles(base, ti, cols, q)
+    assert thr.shape == (n, 365, 10) and not np.isnan(thr).any()
+    assert np.all(np.diff(thr, axis=2) >= 0)
+    sample = rng.choice(n, size=48, replace=False)
+    win = cal.expand_window_table(ti, cols)
+    assert same_f64(thr[sample], core.compute_percentiles_table(base[sample], win, q))
+    assert same_f64(thr[sample], c_oracle.thresholds(base[sample], win, q))
+
+    doy_map = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    is_south = (lat < 0).astype(np.uint8)
+    split = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
+    monkeypatch.setenv("HDP_METRICS_FUSED", "1")
+    fused = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
+    monkeypatch.delenv("HDP_METRICS_FUSED")
+    monkeypatch.setenv("HDP_METRICS_GENERAL", "1")
+    general = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
+    monkeypatch.delenv("HDP_METRICS_GENERAL")
+    assert np.array_equal(split, fused) and np.array_equal(split, general)
+    hwf, hwn, hwd, hwa = (split[:, :, :, i, :].astype(np.int64) for i in range(4))
+    assert hwf.min() >= 0 and np.all(hwf >= hwd) and np.all(hwd >= hwa) and np.all(hwn <= hwf)
+    assert np.array_equal(hwa, np.where(hwn > 0, hwf // np.maximum(hwn, 1), 0))
+    assert np.all(hwf[hwn == 0] == 0) and hwf.max() <= 153 and hwf.sum() > 0
+    want = c_oracle.metrics(meas[sample], thr[sample], doy_map, defs, north, south, is_south[sample])
+    assert np.array_equal(split[:, :, sample].astype(np.int64), want)
