@@ -92,6 +92,7 @@ struct hdp_threshold_plan {
   hdp::DevBuf cols_local;  // uint16 [n_doy][W] local column of each window member
   hdp::DevBuf qparam;      // QuantileParam [P]
   hdp::DevBuf tgt_top, tgt_bot;  // int2 (rank, slot) sorted by rank
+  mutable hdp::DevBuf clk;       // HDP_THR_DEBUG=8 phase clocks
 };
 
 struct hdp_metrics_plan {

@@ -36,7 +36,8 @@ struct ThrDev {
   const int2 *tgt_top, *tgt_bot;
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
-  int debug;  // timing ablations only (HDP_THR_DEBUG): 1 = no merge, 2 = no sort, 4 = no load
+  int debug;  // timing ablations only (HDP_THR_DEBUG): 1 = no merge, 2 = no sort, 4 = no load, 8 = phase clocks
+  unsigned long long *clk;  // [4] accumulated s_memtime ticks of wave 0: load, sort, merge, blocks (debug & 8)
 };
 
 constexpr int kThrThreads = 256;
@@ -453,15 +454,17 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
     const int2 *list = pd.load_list + pd.blk_list_off[b];
     const int llen = pd.blk_list_len[b];
 
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+    if (pd.debug & 8) t_a = __builtin_readcyclecounter();
     // 1. sentinels + load
     for (int i = tid; i < ncols; i += kThrThreads) {
       colbuf[i * pd.S_pad] = __int_as_float(kKeyMax);          // below every ascending walk
       colbuf[i * pd.S_pad + pd.S + 1] = __int_as_float(kKeyMin);  // below every descending walk
     }
-    // batches of kLoadBatch independent (list entry -> sample -> LDS) chains per thread: all list
-    // reads of a batch are issued before the first sample read, all sample reads before the first
-    // LDS write, so a thread keeps kLoadBatch HBM requests in flight instead of one
     if (!(pd.debug & 4)) {
+      // batches of kLoadBatch independent (list entry -> sample -> LDS) chains per thread: all list
+      // reads of a batch are issued before the first sample read, all sample reads before the first
+      // LDS write, so a thread keeps kLoadBatch HBM requests in flight instead of one
       constexpr int kLoadBatch = 8;
       for (int base = tid; base < llen; base += kThrThreads * kLoadBatch) {
         int2 e[kLoadBatch];
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
       }
     }
     __syncthreads();
+    if (pd.debug & 8) t_b = __builtin_readcyclecounter();
 
     // 2. sort every column once
     if (pd.debug & 2) {
@@ -487,6 +491,7 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
         sort_column<EPL>(colbuf + lc * pd.S_pad + 1, pd.S, &flags[lc], lane);
     }
     __syncthreads();
+    if (pd.debug & 8) t_c = __builtin_readcyclecounter();
 
     // 3. + 4. merge and interpolate, one lane per row; every quantile is stored as soon as its
     //         second order statistic comes out of the merge
@@ -511,6 +516,13 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
       }
     }
     __syncthreads();
+    if ((pd.debug & 8) && tid == 0) {
+      t_d = __builtin_readcyclecounter();
+      atomicAdd(&pd.clk[0], t_b - t_a);
+      atomicAdd(&pd.clk[1], t_c - t_b);
+      atomicAdd(&pd.clk[2], t_d - t_c);
+      atomicAdd(&pd.clk[3], 1ull);
+    }
   }
 }
 
@@ -647,6 +659,14 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.nt_bot = plan->nt_bot;
   pd.n = (int)plan->n;
   pd.debug = getenv("HDP_THR_DEBUG") ? atoi(getenv("HDP_THR_DEBUG")) : 0;
+  pd.clk = nullptr;
+  if (pd.debug & 8) {
+    if (plan->clk.bytes == 0) {
+      HDP_HIP_TRY(plan->clk.alloc(4 * sizeof(unsigned long long)));
+      HDP_HIP_TRY(hipMemset(plan->clk.p, 0, 4 * sizeof(unsigned long long)));
+    }
+    pd.clk = plan->clk.as<unsigned long long>();
+  }
   switch (plan->epl) {
     case 1: return launch_thr_epl<1>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
     case 2: return launch_thr_epl<2>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
@@ -875,6 +895,12 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
 }
 
 extern "C" int hdp_threshold_plan_destroy(hdp_threshold_plan *plan) {
+  if (plan && plan->clk.bytes) {  // HDP_THR_DEBUG=8: per-phase clocks of the lead wave, summed over blocks
+    unsigned long long c[4] = {0, 0, 0, 0};
+    if (hipMemcpy(c, plan->clk.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && c[3])
+      fprintf(stderr, "[hdp thresholds] blocks=%llu  ticks/block: load=%.0f sort=%.0f merge=%.0f\n", c[3],
+              double(c[0]) / c[3], double(c[1]) / c[3], double(c[2]) / c[3]);
+  }
   delete plan;
   return HDP_OK;
 }
