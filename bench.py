@@ -178,8 +178,19 @@ def main():
                            "cell_days_per_s": bc * T / (ms_met * 1e-3)},
     }
     dom = "thresholds_kernel" if ms_thr >= ms_met else "metrics_kernel"
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process,
+    # so the per-cell figure measured with rocprofv3 (profiles/traffic_per_cell.json, same workload
+    # shape) is scaled to the cells of one launch; null when no profile matches this workload.
+    traffic = None
+    try:
+        tp = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_cell.json")))
+        if tp.get("workload") == args.config:
+            traffic = float(tp[dom]["bytes_per_cell"]) * bc
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kern[dom]["frac_hbm"], "traffic": None,
+                "unit": "GB/s", "frac": kern[dom]["frac_hbm"], "traffic": traffic,
+                "traffic_source": "rocprofv3 FETCH_SIZE/WRITE_SIZE per cell (profiles/) x cells per launch",
                 "both_kernels_frac": (bytes_thr + bytes_met) / (ms_thr + ms_met) / 1e6 / HBM_PEAK_GBS,
                 "measured_copy_ceiling": HBM_COPY_GBS}
 

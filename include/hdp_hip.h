@@ -127,7 +127,7 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy,
                             const int64_t *north, const int64_t *south, int64_t Y,
                             int64_t P, hdp_metrics_plan **plan_out);
 int hdp_metrics_plan_destroy(hdp_metrics_plan *plan);
-/* Row pitch (in int16 elements) of the device output: Y rounded up to 4. */
+/* Row pitch (in int16 elements) of the device output: Y rounded up to 16 (32-byte rows). */
 int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan);
 
 /*
