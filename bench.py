@@ -50,6 +50,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--mem-fraction", type=float, default=0.88)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo only to rehearse the N>1 code path on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (needs --backend gloo and a small --cells)")
     args = ap.parse_args()
 
     import torch
@@ -60,10 +64,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from hdp_amd import _lib, calendar as cal, core, utils
 
@@ -158,7 +167,7 @@ def main():
             _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(ms))); t_thr.append(float(ms.value))
             _lib.check(lib.hdp_event_elapsed_ms(e1, e2, ctypes.byref(ms))); t_met.append(float(ms.value))
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
@@ -201,8 +210,11 @@ def main():
         share = min(out.numel(), total_c4 // 8)                   # the per-GPU shard of config 4
         free_b, _ = torch.cuda.mem_get_info(dev)
         share = int(min(share, free_b * 0.8 / 2 / world))
-        gathered = torch.empty(share * world, dtype=torch.int16, device=dev)
-        g8, o8 = gathered.view(torch.uint8), out[:share].view(torch.uint8)   # RCCL has no int16 type
+        if args.backend != "nccl":   # rehearsal path: gloo moves host bytes
+            share = min(share, 1 << 24)
+        gdev = dev if args.backend == "nccl" else torch.device("cpu")
+        gathered = torch.empty(share * world, dtype=torch.int16, device=gdev)
+        g8, o8 = gathered.view(torch.uint8), out[:share].to(gdev).view(torch.uint8)   # RCCL has no int16 type
         dist.all_gather_into_tensor(g8, o8)
         fence()
         t1 = time.perf_counter()
@@ -237,9 +249,10 @@ def main():
         hemi = (lat_cells[:ns] < 0).astype(np.uint8)
         met_cpu = c_oracle.metrics(xm_h(ns), th_cpu, doy_map, DEFINITIONS, north, south, hemi)
         cpu_s = time.perf_counter() - tc
-        cpu = {"value": 2.0 * ns * T / cpu_s, "unit": "cell-days/s", "cores": cores, "kind": "port",
+        cpu = None if world > 1 else {   # reported at N = 1 only (torchrun pins OMP_NUM_THREADS=1)
+            "value": 2.0 * ns * T / cpu_s, "unit": "cell-days/s", "cores": cores, "kind": "port",
                "sample": f"first {ns} cells of band 0 of the same workload (T={T}, P={P}, D={D}), both passes, "
-                         f"{cpu_s:.1f} s; oracle/hdp_oracle.c (reference algorithm restated in C, OpenMP over cells)"}
+                      f"{cpu_s:.1f} s; oracle/hdp_oracle.c (reference algorithm restated in C, OpenMP over cells)"}
         # the same sample doubles as a parity spot-check of what the timed kernels produced (band 0 flags)
         tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
         mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[0].data_ptr(), bc, out.data_ptr(), stream)
