@@ -59,6 +59,34 @@ static int64_t chunk_cells_for(int64_t n_cells, int64_t bytes_per_cell) {
   return std::min(c, n_cells);
 }
 
+// Bring series [c0, c0+nc) of a strided host array into dx [nc][T] on the device.
+//  - time-contiguous rows: one plain copy;
+//  - time-major (CMIP [time][cells], stride_cell == 1): strided 2-D copy of the [T][nc] slab into
+//    `raw`, then a device transpose -- no host-side repacking of the bulk data;
+//  - anything else: packed on the host.
+struct SeriesUploader {
+  DevBuf raw;
+  std::vector<float> stage;
+  int upload(const float *x, int64_t c0, int64_t nc, int64_t T, int64_t sc, int64_t st, float *dx,
+             hipStream_t stream) {
+    if (st == 1 && sc == T) {
+      HDP_HIP_TRY(hipMemcpyAsync(dx, x + c0 * T, size_t(nc) * T * 4, hipMemcpyHostToDevice, stream));
+      return HDP_OK;
+    }
+    if (sc == 1 && st >= nc) {
+      if (raw.bytes < size_t(nc) * T * 4) HDP_HIP_TRY(raw.alloc(size_t(nc) * T * 4));
+      HDP_HIP_TRY(hipMemcpy2DAsync(raw.p, size_t(nc) * 4, x + c0, size_t(st) * 4, size_t(nc) * 4, size_t(T),
+                                   hipMemcpyHostToDevice, stream));
+      return launch_transpose(raw.as<float>(), nc, T, nc, dx, stream);
+    }
+    if (stage.size() < size_t(nc) * T) stage.resize(size_t(nc) * T);
+    pack_series(x, c0, nc, T, sc, st, stage.data());
+    HDP_HIP_TRY(hipMemcpyAsync(dx, stage.data(), size_t(nc) * T * 4, hipMemcpyHostToDevice, stream));
+    HDP_HIP_TRY(hipStreamSynchronize(stream));  // `stage` is reused by the next chunk
+    return HDP_OK;
+  }
+};
+
 }  // namespace hdp
 
 using namespace hdp;
@@ -201,17 +229,11 @@ int hdp_thresholds_f32(const float *x, int64_t n_cells, int64_t T, int64_t strid
   DevBuf dx, dout;
   HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
   HDP_HIP_TRY(dout.alloc(size_t(chunk) * n_doy * P * 8));
-  std::vector<float> stage;
-  const bool direct = (stride_time == 1 && stride_cell == T);
-  if (!direct) stage.resize(size_t(chunk) * T);
+  SeriesUploader up;
   for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
     const int64_t nc = std::min(chunk, n_cells - c0);
-    const float *src = x + c0 * T;
-    if (!direct) {
-      pack_series(x, c0, nc, T, stride_cell, stride_time, stage.data());
-      src = stage.data();
-    }
-    HDP_HIP_TRY(hipMemcpyAsync(dx.p, src, size_t(nc) * T * 4, hipMemcpyHostToDevice, g_stream));
+    rc = up.upload(x, c0, nc, T, stride_cell, stride_time, dx.as<float>(), g_stream);
+    if (rc != HDP_OK) return rc;
     rc = launch_thresholds(plan, dx.as<float>(), nc, dout.as<double>(), g_stream);
     if (rc != HDP_OK) return rc;
     HDP_HIP_TRY(hipMemcpyAsync(out + c0 * n_doy * P, dout.p, size_t(nc) * n_doy * P * 8,
@@ -247,12 +269,12 @@ int hdp_percentiles_table_f32(const float *x, int64_t n_cells, int64_t T, int64_
   const int64_t chunk = chunk_cells_for(n_cells, T * 4 + n_doy * P * 8);
   HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
   HDP_HIP_TRY(dout.alloc(size_t(chunk) * n_doy * P * 8));
-  std::vector<float> stage(size_t(chunk) * T);
+  SeriesUploader up;
   for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
     const int64_t nc = std::min(chunk, n_cells - c0);
-    pack_series(x, c0, nc, T, stride_cell, stride_time, stage.data());
-    HDP_HIP_TRY(hipMemcpyAsync(dx.p, stage.data(), size_t(nc) * T * 4, hipMemcpyHostToDevice, g_stream));
-    int rc = launch_table_percentiles(dx.as<float>(), nc, T, dwin.as<int64_t>(), n_doy, B,
+    int rc = up.upload(x, c0, nc, T, stride_cell, stride_time, dx.as<float>(), g_stream);
+    if (rc != HDP_OK) return rc;
+    rc = launch_table_percentiles(dx.as<float>(), nc, T, dwin.as<int64_t>(), n_doy, B,
                                       dqp.as<QuantileParam>(), dklo.as<int32_t>(), dkhi.as<int32_t>(), P,
                                       dout.as<double>(), g_stream);
     if (rc != HDP_OK) return rc;
@@ -376,18 +398,12 @@ int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_c
   HDP_HIP_TRY(dsouth.alloc(size_t(chunk)));
   HDP_HIP_TRY(dout.alloc(size_t(4) * P * D * chunk * Yp * 2));
   HDP_HIP_TRY(dref.alloc(size_t(4) * P * D * chunk * Y * 2));
-  std::vector<float> stage;
-  const bool direct = (stride_time == 1 && stride_cell == T);
-  if (!direct) stage.resize(size_t(chunk) * T);
+  SeriesUploader up;
   std::vector<int16_t> host_ref(size_t(4) * P * D * chunk * Y);
   for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
     const int64_t nc = std::min(chunk, n_cells - c0);
-    const float *src = x + c0 * T;
-    if (!direct) {
-      pack_series(x, c0, nc, T, stride_cell, stride_time, stage.data());
-      src = stage.data();
-    }
-    HDP_HIP_TRY(hipMemcpyAsync(dx.p, src, size_t(nc) * T * 4, hipMemcpyHostToDevice, g_stream));
+    rc = up.upload(x, c0, nc, T, stride_cell, stride_time, dx.as<float>(), g_stream);
+    if (rc != HDP_OK) return rc;
     HDP_HIP_TRY(hipMemcpyAsync(dsouth.p, is_south + c0, size_t(nc), hipMemcpyHostToDevice, g_stream));
     // with shared thresholds c0 is a multiple of n_thr_cells, so the modulo mapping is unchanged
     const double *thr_base = dthr.as<double>() + (n_thr_cells == n_cells ? c0 * n_doy * P : 0);

@@ -722,6 +722,37 @@ __global__ void season_metrics_kernel(const int64_t *__restrict__ ids, int64_t n
   hwa[s * Y + y] = mean;
 }
 
+// ---- layout: time-major [T][n] (CMIP order) -> series-major [n][T] ---------------------------
+// 64 x 64 tiles through LDS (pitch 65: conflict-free both ways); reads are coalesced along the
+// cell axis, writes along time.  HBM-bound: 8 bytes of traffic per element.
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, int64_t src_pitch,
+                                                        int64_t T, int64_t n, float *__restrict__ dst) {
+  __shared__ float tile[64][65];
+  const int64_t t0 = int64_t(blockIdx.y) * 64, c0 = int64_t(blockIdx.x) * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;  // 64 x 4 threads
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t t = t0 + ly + 4 * i, c = c0 + lx;
+    if (t < T && c < n) tile[ly + 4 * i][lx] = src[t * src_pitch + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t c = c0 + ly + 4 * i, t = t0 + lx;
+    if (t < T && c < n) dst[c * T + t] = tile[lx][ly + 4 * i];
+  }
+}
+
+int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
+                     hipStream_t stream) {
+  if (T * n == 0) return HDP_OK;
+  dim3 grid((unsigned)((n + 63) / 64), (unsigned)((T + 63) / 64));
+  HDP_REQUIRE(grid.y < 65536, HDP_EUNSUP, "time axis too long for the transpose launch");
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
 // ---- synthetic series (reference generator formula, hdp/utils.py:61-78,41) -------------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
   z += 0x9e3779b97f4a7c15ULL;

@@ -406,3 +406,29 @@ def test_c2_full_size_cross_kernel_properties(monkeypatch):
     assert np.all(hwf[hwn == 0] == 0) and hwf.max() <= 153 and hwf.sum() > 0
     want = c_oracle.metrics(meas[sample], thr[sample], doy_map, defs, north, south, is_south[sample])
     assert np.array_equal(split[:, :, sample].astype(np.int64), want)
+
+
+def test_time_major_inputs_through_device_transpose():
+    """CMIP order [time, cells] (stride_cell == 1): strided 2-D upload + device transpose must give
+    exactly what the time-contiguous copy gives, for both passes; odd sizes exercise tile edges."""
+    rng = np.random.default_rng(17)
+    dates = orc.noleap_date_range("2001-01-01", "2004-12-31")
+    T, n = dates.size, 131
+    xt = rng.normal(1.0, 2.0, size=(T, n)).astype(np.float32)
+    ti, cols = cal.window_columns(dates, 7)
+    q = [0.9, 0.97]
+    thr_a = core.compute_percentiles(xt.T, ti, cols, q)
+    thr_b = core.compute_percentiles(np.ascontiguousarray(xt.T), ti, cols, q)
+    assert same_f64(thr_a, thr_b)
+    dm = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    hemi = (np.arange(n) % 3 == 0).astype(np.uint8)
+    defs = [[3, 0, 0], [2, 1, 1]]
+    met_a = core.compute_heatwave_metrics(xt.T, thr_a, dm, defs, north, south, hemi)
+    met_b = core.compute_heatwave_metrics(np.ascontiguousarray(xt.T), thr_a, dm, defs, north, south, hemi)
+    assert np.array_equal(met_a, met_b)
+    # a column slice of a wider time-major array (stride_time > n)
+    wide = rng.normal(size=(T, n + 40)).astype(np.float32)
+    sub = wide[:, 7:7 + n]
+    assert same_f64(core.compute_percentiles(sub.T, ti, cols, q),
+                    core.compute_percentiles(np.ascontiguousarray(sub.T), ti, cols, q))
