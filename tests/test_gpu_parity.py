@@ -432,3 +432,32 @@ def test_time_major_inputs_through_device_transpose():
     sub = wide[:, 7:7 + n]
     assert same_f64(core.compute_percentiles(sub.T, ti, cols, q),
                     core.compute_percentiles(np.ascontiguousarray(sub.T), ti, cols, q))
+
+
+def test_c5_shaped_ensemble_thresholds_and_metrics():
+    """Config 5 shape at small grid: 10 members x 100 years concatenated along time for thresholds
+    (S = 1000 samples per day of year, window of 15000 samples, generic wide-column sort path),
+    20 percentiles x 12 definitions = 240 lane pairs, members sharing their cell's thresholds."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(55)
+    dates = orc.noleap_date_range("2001-01-01", "2100-12-31")
+    T, members, n_cells = dates.size, 10, 3
+    x = rng.normal(12, 3, size=(members, n_cells, T)).astype(np.float32)
+    x += (np.arange(T, dtype=np.float32) / np.float32(36500.0))[None, None, :]
+    cat = np.concatenate([x[m] for m in range(members)], axis=1)          # [cells, members*T]
+    cdates = np.concatenate([dates] * members)
+    ti, cols = cal.window_columns(cdates, 7)
+    assert ti.shape == (365, 1000)
+    q = np.linspace(0.80, 0.99, 20)
+    thr = core.compute_percentiles(cat, ti, cols, q)
+    rows = [0, 3, 182, 357, 358, 364]
+    win = cal.expand_window_table(ti, cols)[rows]
+    assert same_f64(thr[:, rows], c_oracle.thresholds(cat, win, q))
+    defs = [[a, b, b] for a in (3, 4, 5, 6) for b in (0, 1, 2)]
+    dm = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    series = x.reshape(members * n_cells, T)                                # member-major
+    hemi = np.tile(np.array([0, 1, 0], dtype=np.uint8), members)
+    got = core.compute_heatwave_metrics(series, thr, dm, defs, north, south, hemi)
+    want = c_oracle.metrics(series, np.concatenate([thr] * members), dm, defs, north, south, hemi)
+    assert np.array_equal(got.astype(np.int64), want)
