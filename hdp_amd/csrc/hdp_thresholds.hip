@@ -151,7 +151,11 @@ __device__ __forceinline__ void reg_tail(float (&v)[8]) {  // half-cleaners at d
   ce_reg(v[0], v[1]); ce_reg(v[2], v[3]); ce_reg(v[4], v[5]); ce_reg(v[6], v[7]);
 }
 
-__device__ __forceinline__ void sort_row128_desc(float (&v)[8], int l /* lane within the row */) {
+// LPC = lanes per column (1, 2, 4, 8, 16): a column of up to 8*LPC keys is spread over LPC
+// neighbouring lanes (8 keys each), so a wave sorts 64/LPC columns at once and short columns
+// (few years of data) do not pay for the full 128-key network.
+template <int LPC>
+__device__ __forceinline__ void sort_group_desc(float (&v)[8], int l /* lane within the column group */) {
   // k = 2, 4, 8: inside the lane
   ce_reg(v[0], v[1]); ce_reg(v[2], v[3]); ce_reg(v[4], v[5]); ce_reg(v[6], v[7]);
   ce_reg(v[0], v[3]); ce_reg(v[1], v[2]); ce_reg(v[4], v[7]); ce_reg(v[5], v[6]);
@@ -161,31 +165,36 @@ __device__ __forceinline__ void sort_row128_desc(float (&v)[8], int l /* lane wi
   ce_reg(v[0], v[1]); ce_reg(v[2], v[3]); ce_reg(v[4], v[5]); ce_reg(v[6], v[7]);
   const float b0 = (l & 1) ? -INFINITY : INFINITY, b1 = (l & 2) ? -INFINITY : INFINITY;
   const float b2 = (l & 4) ? -INFINITY : INFINITY, b3 = (l & 8) ? -INFINITY : INFINITY;
-  // k = 16
-  ce_cross<1, true>(v, b0);
-  reg_tail(v);
-  // k = 32
-  ce_cross<3, true>(v, b1);
-  ce_cross<1, false>(v, b0);
-  reg_tail(v);
-  // k = 64
-  ce_cross<7, true>(v, b2);
-  ce_cross<2, false>(v, b1);
-  ce_cross<1, false>(v, b0);
-  reg_tail(v);
-  // k = 128
-  ce_cross<15, true>(v, b3);
-  ce_cross<4, false>(v, b2);
-  ce_cross<2, false>(v, b1);
-  ce_cross<1, false>(v, b0);
-  reg_tail(v);
+  if constexpr (LPC >= 2) {  // k = 16
+    ce_cross<1, true>(v, b0);
+    reg_tail(v);
+  }
+  if constexpr (LPC >= 4) {  // k = 32
+    ce_cross<3, true>(v, b1);
+    ce_cross<1, false>(v, b0);
+    reg_tail(v);
+  }
+  if constexpr (LPC >= 8) {  // k = 64
+    ce_cross<7, true>(v, b2);
+    ce_cross<2, false>(v, b1);
+    ce_cross<1, false>(v, b0);
+    reg_tail(v);
+  }
+  if constexpr (LPC >= 16) {  // k = 128
+    ce_cross<15, true>(v, b3);
+    ce_cross<4, false>(v, b2);
+    ce_cross<2, false>(v, b1);
+    ce_cross<1, false>(v, b0);
+    reg_tail(v);
+  }
 }
 
-// Sort up to four LDS columns (lc0 + row, row = lane / 16) at once; S <= 128.
+// Sort 64/LPC LDS columns (lc0 + lane / LPC) at once; S <= 8 * LPC.
+template <int LPC>
 __device__ __forceinline__ void sort_columns_rows(float *colbuf, int S_pad, int S, int lc0, int ncols,
                                                   uint32_t *flags, int lane) {
-  const int row = lane >> 4, l = lane & 15;
-  const int lc = lc0 + row;
+  const int grp = lane / LPC, l = lane % LPC;
+  const int lc = lc0 + grp;
   const bool active = lc < ncols;
   float *col = colbuf + (active ? lc : lc0) * S_pad + 1;
   float v[8];
@@ -200,19 +209,27 @@ __device__ __forceinline__ void sort_columns_rows(float *colbuf, int S_pad, int 
     if (real && x == -INFINITY) cnt += 1u;
     v[i] = x;
   }
-  sort_row128_desc(v, l);
+  sort_group_desc<LPC>(v, l);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int e = l * 8 + i;
     if (active && e < S) col[e] = __int_as_float(f32_key(v[i]));
   }
-  // row-wide sum of the packed counters (each field < 1024)
-  cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor1, 0xf, 0xf, false);
-  cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor2, 0xf, 0xf, false);
-  cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppHalfMirror, 0xf, 0xf, false);
-  cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppMirror, 0xf, 0xf, false);
+  // group-wide sum of the packed counters (each field < 1024)
+  if constexpr (LPC >= 2) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor1, 0xf, 0xf, false);
+  if constexpr (LPC >= 4) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor2, 0xf, 0xf, false);
+  if constexpr (LPC >= 8) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppHalfMirror, 0xf, 0xf, false);
+  if constexpr (LPC >= 16) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppMirror, 0xf, 0xf, false);
   if (active && l == 0)
     flags[lc] = ((cnt >> 20) ? 0x80000000u : 0u) | (((cnt >> 10) & 0x3ffu) << 15) | (cnt & 0x3ffu);
+}
+
+template <int LPC>
+__device__ __forceinline__ void sort_block_rows(float *colbuf, int S_pad, int S, int ncols, uint32_t *flags,
+                                                int wave, int nwaves, int lane) {
+  constexpr int kCols = 64 / LPC;
+  for (int lc0 = wave * kCols; lc0 < ncols; lc0 += nwaves * kCols)
+    sort_columns_rows<LPC>(colbuf, S_pad, S, lc0, ncols, flags, lane);
 }
 
 // Sort one LDS column (S values at col[0..S)) descending; NaN -> flagged and replaced
@@ -484,8 +501,11 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
     // 2. sort every column once
     if (pd.debug & 2) {
     } else if (pd.S <= 128 && EPL <= 2) {
-      for (int lc0 = wave * 4; lc0 < ncols; lc0 += nwaves * 4)
-        sort_columns_rows(colbuf, pd.S_pad, pd.S, lc0, ncols, flags, lane);
+      if (pd.S <= 8) sort_block_rows<1>(colbuf, pd.S_pad, pd.S, ncols, flags, wave, nwaves, lane);
+      else if (pd.S <= 16) sort_block_rows<2>(colbuf, pd.S_pad, pd.S, ncols, flags, wave, nwaves, lane);
+      else if (pd.S <= 32) sort_block_rows<4>(colbuf, pd.S_pad, pd.S, ncols, flags, wave, nwaves, lane);
+      else if (pd.S <= 64) sort_block_rows<8>(colbuf, pd.S_pad, pd.S, ncols, flags, wave, nwaves, lane);
+      else sort_block_rows<16>(colbuf, pd.S_pad, pd.S, ncols, flags, wave, nwaves, lane);
     } else {
       for (int lc = wave; lc < ncols; lc += nwaves)
         sort_column<EPL>(colbuf + lc * pd.S_pad + 1, pd.S, &flags[lc], lane);
