@@ -341,8 +341,9 @@ __device__ __forceinline__ void emit_targets(const ThrDev &pd, const int2 *tgt, 
 // parameter (NG = 0: generic rescan loop for very wide windows).
 template <bool TOP, int NG>
 __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_f, float *hbuf_f,
-                                          uint32_t *posb, const uint16_t *cl, int r /* row within block */,
-                                          const RowFlags &rf, bool store, double *orow) {
+                                          uint32_t *posb, const uint16_t *cl, const int *clr,
+                                          int r /* row within block */, const RowFlags &rf, bool store,
+                                          double *orow) {
   const int *colbuf = reinterpret_cast<const int *>(colbuf_f);
   int *hbuf = reinterpret_cast<int *>(hbuf_f);
   const int RP = pd.RP;
@@ -351,16 +352,32 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
   const int2 *tgt = TOP ? pd.tgt_top : pd.tgt_bot;
   if (steps == 0) return;
   const int worst = TOP ? kKeyMin : kKeyMax;
-  for (int j = 0; j < pd.Wp; ++j) {
-    const int idx = ((j >> 2) * RP + r) * 4 + (j & 3);
-    int h = worst;
-    int pos = 0;
-    if (j < pd.W) {
-      pos = int(cl[j]) * pd.S_pad + (TOP ? 1 : pd.S);
-      h = colbuf[pos];
+  if constexpr (NG > 0) {
+    // clr: the row's local column ids, already in registers (one batch of independent loads)
+    int pos[4 * NG], hv[4 * NG];
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) {
+      pos[j] = (j < pd.W) ? clr[j] * pd.S_pad + (TOP ? 1 : pd.S) : 0;
+      hv[j] = (j < pd.W) ? colbuf[pos[j]] : worst;
     }
-    hbuf[idx] = h;
-    posb[idx] = (uint32_t(pos) << 8) | uint32_t(j);
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) {
+      const int idx = ((j >> 2) * RP + r) * 4 + (j & 3);
+      hbuf[idx] = hv[j];
+      posb[idx] = (uint32_t(pos[j]) << 8) | uint32_t(j);
+    }
+  } else {
+    for (int j = 0; j < pd.Wp; ++j) {
+      const int idx = ((j >> 2) * RP + r) * 4 + (j & 3);
+      int h = worst;
+      int pos = 0;
+      if (j < pd.W) {
+        pos = int(cl[j]) * pd.S_pad + (TOP ? 1 : pd.S);
+        h = colbuf[pos];
+      }
+      hbuf[idx] = h;
+      posb[idx] = (uint32_t(pos) << 8) | uint32_t(j);
+    }
   }
   int4 *hb4 = reinterpret_cast<int4 *>(hbuf);
   uint4 *pb4 = reinterpret_cast<uint4 *>(posb);
@@ -434,10 +451,33 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
 
 template <int NG>
 __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf, float *hbuf, uint32_t *posb,
-                                           const uint16_t *cl, int r, const RowFlags &rf, bool store,
+                                           const uint32_t *flags, const uint16_t *cl, int r, bool store,
                                            double *orow) {
-  merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
-  merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+  // the row's column list: one batch of independent loads into registers (NG > 0)
+  int clr[NG > 0 ? 4 * NG : 1];
+  if constexpr (NG > 0) {
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) clr[j] = (j < pd.W) ? int(cl[j]) : 0;
+  }
+  RowFlags rf{false, 0, 0};
+  if constexpr (NG > 0) {
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) {
+      const uint32_t f = (j < pd.W) ? flags[clr[j]] : 0u;
+      rf.has_nan |= (f >> 31) != 0;
+      rf.n_pos += (f >> 15) & 0x7fff;
+      rf.n_neg += f & 0x7fff;
+    }
+  } else {
+    for (int j = 0; j < pd.W; ++j) {
+      const uint32_t f = flags[cl[j]];
+      rf.has_nan |= (f >> 31) != 0;
+      rf.n_pos += (f >> 15) & 0x7fff;
+      rf.n_neg += f & 0x7fff;
+    }
+  }
+  merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, clr, r, rf, store, orow);
+  merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, clr, r, rf, store, orow);
 }
 
 template <int EPL>
@@ -518,20 +558,13 @@ __global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, cons
     if (tid < nrows) {
       const int row = row0 + tid;
       const uint16_t *cl = pd.cols_local + size_t(row) * pd.W;
-      RowFlags rf{false, 0, 0};
-      for (int j = 0; j < pd.W; ++j) {
-        const uint32_t f = flags[cl[j]];
-        rf.has_nan |= (f >> 31) != 0;
-        rf.n_pos += (f >> 15) & 0x7fff;
-        rf.n_neg += f & 0x7fff;
-      }
       double *orow = out + (cell * pd.n_doy + row) * int64_t(pd.P);
       if (!(pd.debug & 1)) {
         switch (pd.Wp >> 2) {
-          case 1: merge_both<1>(pd, colbuf, hbuf, posb, cl, tid, rf, true, orow); break;
-          case 2: merge_both<2>(pd, colbuf, hbuf, posb, cl, tid, rf, true, orow); break;
-          case 4: merge_both<4>(pd, colbuf, hbuf, posb, cl, tid, rf, true, orow); break;
-          default: merge_both<0>(pd, colbuf, hbuf, posb, cl, tid, rf, true, orow); break;
+          case 1: merge_both<1>(pd, colbuf, hbuf, posb, flags, cl, tid, true, orow); break;
+          case 2: merge_both<2>(pd, colbuf, hbuf, posb, flags, cl, tid, true, orow); break;
+          case 4: merge_both<4>(pd, colbuf, hbuf, posb, flags, cl, tid, true, orow); break;
+          default: merge_both<0>(pd, colbuf, hbuf, posb, flags, cl, tid, true, orow); break;
         }
       }
     }
