@@ -101,6 +101,10 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf,
                                                      BANK_MASK, false));
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov1(float src) {  // every lane is written: no `old` to preserve
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(src), CTRL, 0xf, 0xf, true));
+}
 constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int kDppXor3 = 0x1B;         // quad_perm [3,2,1,0]
@@ -110,11 +114,11 @@ constexpr int kDppShl4 = 0x104, kDppShr4 = 0x114;
 
 template <int XOR>
 __device__ __forceinline__ float row_xor(float v) {
-  if constexpr (XOR == 1) return dpp_mov<kDppXor1>(v, v);
-  else if constexpr (XOR == 2) return dpp_mov<kDppXor2>(v, v);
-  else if constexpr (XOR == 3) return dpp_mov<kDppXor3>(v, v);
-  else if constexpr (XOR == 7) return dpp_mov<kDppHalfMirror>(v, v);
-  else if constexpr (XOR == 15) return dpp_mov<kDppMirror>(v, v);
+  if constexpr (XOR == 1) return dpp_mov1<kDppXor1>(v);
+  else if constexpr (XOR == 2) return dpp_mov1<kDppXor2>(v);
+  else if constexpr (XOR == 3) return dpp_mov1<kDppXor3>(v);
+  else if constexpr (XOR == 7) return dpp_mov1<kDppHalfMirror>(v);
+  else if constexpr (XOR == 15) return dpp_mov1<kDppMirror>(v);
   else {  // XOR == 4: lanes 0-3, 8-11 read lane+4; lanes 4-7, 12-15 read lane-4
     static_assert(XOR == 4, "unsupported row xor");
     float t = dpp_mov<kDppShl4, 0x5>(v, v);
@@ -199,15 +203,24 @@ __device__ __forceinline__ void sort_columns_rows(float *colbuf, int S_pad, int 
   float *col = colbuf + (active ? lc : lc0) * S_pad + 1;
   float v[8];
   uint32_t cnt = 0;  // nan << 20 | +inf << 10 | -inf
+  bool special = false;  // exponent all ones: NaN or infinity (rare; counted only when present)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int e = l * 8 + i;
-    float x = (active && e < S) ? col[e] : -INFINITY;
     const bool real = active && e < S;
-    if (x != x) { cnt += 1u << 20; x = 0.0f; }
-    if (real && x == INFINITY) cnt += 1u << 10;
-    if (real && x == -INFINITY) cnt += 1u;
-    v[i] = x;
+    v[i] = real ? col[e] : -INFINITY;
+    special |= real && ((__float_as_uint(v[i]) & 0x7f800000u) == 0x7f800000u);
+  }
+  if (__ballot(special) != 0) {  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool real = active && (l * 8 + i) < S;
+      float x = v[i];
+      if (x != x) { cnt += 1u << 20; x = 0.0f; }
+      if (real && x == INFINITY) cnt += 1u << 10;
+      if (real && x == -INFINITY) cnt += 1u;
+      v[i] = x;
+    }
   }
   sort_group_desc<LPC>(v, l);
 #pragma unroll
@@ -389,13 +402,13 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
     uint32_t pay[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) group_winner<TOP>(hb4[g * RP + r], pb4[g * RP + r], m[g], pay[g]);
+    int best = m[0];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) best = kbest<TOP>(best, m[g]);
+    uint32_t bp = pay[0];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) bp = (m[g] == best) ? pay[g] : bp;
     for (int step = 0; step < steps; ++step) {
-      int best = m[0];
-#pragma unroll
-      for (int g = 1; g < NG; ++g) best = kbest<TOP>(best, m[g]);
-      uint32_t bp = pay[0];
-#pragma unroll
-      for (int g = 1; g < NG; ++g) bp = (m[g] == best) ? pay[g] : bp;
       if (step == next_rank) {  // wave-uniform
         emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, best, prev, rf, store, orow);
         next_rank = __builtin_amdgcn_readfirstlane(next_rank);
@@ -409,7 +422,18 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
       const int nk = colbuf[p];  // the column's sentinel once it is exhausted
       int4 h = hb4[gidx];
       uint4 q = pb4[gidx];
+      // --- in the shadow of those reads: the runner-up among the OTHER groups -----------------
+      int ru = worst;
+      uint32_t rup = 0;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int mo = (gw == g) ? worst : m[g];
+        const bool t = TOP ? (mo >= ru) : (mo <= ru);
+        ru = t ? mo : ru;
+        rup = t ? pay[g] : rup;
+      }
       const uint32_t np = (uint32_t(p) << 8) | uint32_t(bj);
+      // --- needs the loaded data -----------------------------------------------------------------
       h.x = (jw == 0) ? nk : h.x; q.x = (jw == 0) ? np : q.x;
       h.y = (jw == 1) ? nk : h.y; q.y = (jw == 1) ? np : q.y;
       h.z = (jw == 2) ? nk : h.z; q.z = (jw == 2) ? np : q.z;
@@ -419,6 +443,9 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
       int mg;
       uint32_t pg;
       group_winner<TOP>(h, q, mg, pg);
+      const bool tw = TOP ? (mg >= ru) : (mg <= ru);
+      best = tw ? mg : ru;
+      bp = tw ? pg : rup;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         m[g] = (gw == g) ? mg : m[g];
