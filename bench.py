@@ -203,6 +203,24 @@ def main():
                 "both_kernels_frac": (bytes_thr + bytes_met) / (ms_thr + ms_met) / 1e6 / HBM_PEAK_GBS,
                 "measured_copy_ceiling": HBM_COPY_GBS}
 
+    # ---- pre-step: fused Celsius -> heat index -> Celsius kernel, reported beside `value`
+    pre_step = None
+    if rank == 0:
+        n_el = int(min(bc * T, thr.numel() // 4, out.numel() // 2, 1 << 30)) & ~3
+        e0, e1 = lib.hdp_event_create(), lib.hdp_event_create()
+        rh_buf = thr[: n_el * 4]      # reuse resident scratch as (arbitrary) humidity / output operands
+        lib.hdp_heat_index_celsius_f32_dev(xm.data_ptr(), rh_buf.data_ptr(), n_el, out.data_ptr(), stream)
+        lib.hdp_event_record(e0, stream)
+        reps = 5
+        for _ in range(reps):
+            _lib.check(lib.hdp_heat_index_celsius_f32_dev(xm.data_ptr(), rh_buf.data_ptr(), n_el, out.data_ptr(), stream))
+        lib.hdp_event_record(e1, stream)
+        hms = ctypes.c_float()
+        _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(hms)))
+        gbps = 12.0 * n_el * reps / (hms.value * 1e-3) / 1e9      # 2 x 4 B read + 4 B written per element
+        pre_step = {"kernel": "heat_index_kernel<celsius>", "elements": n_el, "ms": hms.value / reps,
+                    "GBps": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
+
     # ---- RCCL all-gather of the metrics (reassembly step of north_star), reported separately ------------
     allgather = None
     if world > 1:
@@ -274,7 +292,7 @@ def main():
                        "cells_per_gpu": int(cells_rank_eff), "T": T, "percentiles": P, "definitions": D,
                        "seasons": int(Y), "resident_bands_per_step": n_bands, "cells_per_band": int(bc),
                        "sharding": "independent grid cells per rank, no data-path collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "allgather": allgather,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "pre_step": pre_step, "allgather": allgather,
             "parity_sample": parity, "device": _lib.device_info(),
         }
         print(json.dumps(line))

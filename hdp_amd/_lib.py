@@ -58,6 +58,9 @@ SIGNATURES = {
     "hdp_index_heatwaves": (C.c_int, [vp, i64, i64, i64, i64, i64, vp]),
     "hdp_season_metrics": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
     "hdp_indicate_hot_days": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
+    "hdp_heat_index_f32": (C.c_int, [vp, vp, i64, vp]),
+    "hdp_heat_index_f32_dev": (C.c_int, [vp, vp, i64, vp, vp]),
+    "hdp_heat_index_celsius_f32_dev": (C.c_int, [vp, vp, i64, vp, vp]),
     "hdp_generate_series_dev": (C.c_int, [vp, i64, i64, i64, vp, C.c_uint64, f32, f32, vp]),
 }
 

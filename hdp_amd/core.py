@@ -153,6 +153,17 @@ def indicate_hot_days(measure, threshold, doy_map):
     return hot[0] if one else hot
 
 
+def heat_index(temp, rel_humid):
+    """NWS heat index, element-wise (the ufunc hdp.measure.heat_index, measure.py:61-94):
+    temp [deg F] and rel_humid [%] float32 arrays of one shape -> float32 [deg F]."""
+    lib = _lib.ensure_device()
+    t = np.ascontiguousarray(temp, dtype=np.float32)
+    r = np.ascontiguousarray(np.broadcast_to(np.asarray(rel_humid, dtype=np.float32), t.shape))
+    out = np.empty(t.shape, dtype=np.float32)
+    _lib.check(lib.hdp_heat_index_f32(_ptr(t), _ptr(r), t.size, _ptr(out)))
+    return out
+
+
 # ---- device-resident interface (bench.py, sharded runs) ----------------------------------
 
 class DeviceArray:

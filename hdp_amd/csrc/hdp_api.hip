@@ -494,6 +494,41 @@ int hdp_indicate_hot_days(const float *measure, int64_t n_series, int64_t T, con
   return HDP_OK;
 }
 
+int hdp_heat_index_f32_dev(const float *temp_f_dev, const float *rel_humid_dev, int64_t n, float *out_dev,
+                           void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n >= 0 && (n == 0 || (temp_f_dev && rel_humid_dev && out_dev)), HDP_EINVAL, "bad arguments");
+  return launch_heat_index(temp_f_dev, rel_humid_dev, n, out_dev, false, pick(stream));
+}
+
+int hdp_heat_index_celsius_f32_dev(const float *temp_c_dev, const float *rel_humid_dev, int64_t n,
+                                   float *out_c_dev, void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n >= 0 && (n == 0 || (temp_c_dev && rel_humid_dev && out_c_dev)), HDP_EINVAL, "bad arguments");
+  return launch_heat_index(temp_c_dev, rel_humid_dev, n, out_c_dev, true, pick(stream));
+}
+
+int hdp_heat_index_f32(const float *temp_f, const float *rel_humid, int64_t n, float *out) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n >= 0 && (n == 0 || (temp_f && rel_humid && out)), HDP_EINVAL, "bad arguments");
+  const int64_t chunk = int64_t(1) << 27;  // 512 MiB per operand
+  DevBuf dt, dr, dout;
+  const int64_t cap = std::min(n, chunk);
+  HDP_HIP_TRY(dt.alloc(size_t(cap) * 4));
+  HDP_HIP_TRY(dr.alloc(size_t(cap) * 4));
+  HDP_HIP_TRY(dout.alloc(size_t(cap) * 4));
+  for (int64_t i0 = 0; i0 < n; i0 += chunk) {
+    const int64_t m = std::min(chunk, n - i0);
+    HDP_HIP_TRY(hipMemcpyAsync(dt.p, temp_f + i0, size_t(m) * 4, hipMemcpyHostToDevice, g_stream));
+    HDP_HIP_TRY(hipMemcpyAsync(dr.p, rel_humid + i0, size_t(m) * 4, hipMemcpyHostToDevice, g_stream));
+    int rc = launch_heat_index(dt.as<float>(), dr.as<float>(), m, dout.as<float>(), false, g_stream);
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipMemcpyAsync(out + i0, dout.p, size_t(m) * 4, hipMemcpyDeviceToHost, g_stream));
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  }
+  return HDP_OK;
+}
+
 int hdp_generate_series_dev(float *x_dev, int64_t n_cells, int64_t T, int64_t cell_offset,
                             const float *lat_dev, uint64_t seed, float noise_scale, float trend_per_day,
                             void *stream) {

@@ -127,6 +127,8 @@ int launch_indicate_hot_days(const float *x_dev, int64_t n_series, int64_t T, co
                              hipStream_t stream);
 int launch_generate(float *x_dev, int64_t n_cells, int64_t T, int64_t cell_offset, const float *lat_dev,
                     uint64_t seed, float noise_scale, float trend_per_day, hipStream_t stream);
+int launch_heat_index(const float *temp_dev, const float *rh_dev, int64_t n, float *out_dev, bool celsius,
+                      hipStream_t stream);
 int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
                      hipStream_t stream);
 int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,

@@ -22,6 +22,7 @@
 //   4*T (measure) + 8*n_doy*P (thresholds) + 2*4*Y*P*D (metrics).
 #include "hdp_internal.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -720,6 +721,71 @@ __global__ void season_metrics_kernel(const int64_t *__restrict__ ids, int64_t n
   o[2 * Y + y] = longest;
   o[3 * Y + y] = (int64_t)mean;
   hwa[s * Y + y] = mean;
+}
+
+// ---- heat index (hdp/measure.py:61-94), element-wise, HBM-bound ------------------------------
+// float64 arithmetic in the order the reference writes it (Numba types the float32 arguments
+// against float64 literals), one float32 product (rel_humid*temp) as in the reference's last term.
+__device__ __forceinline__ float heat_index_f(float temp, float rel_humid) {
+  const double t = (double)temp, r = (double)rel_humid;
+  double hi = 0.5 * (t + 61.0 + ((t - 68.0) * 1.2) + (r * 0.094));
+  if (hi > 80.0) {
+    hi = -42.379;
+    hi += 2.04901523 * t;
+    hi += 10.14333127 * r;
+    hi += -0.22475541 * t * r;
+    hi += -0.00683783 * (t * t);
+    hi += -0.05481717 * (r * r);
+    hi += 0.00122874 * (t * t) * r;
+    hi += 0.00085282 * t * (r * r);
+    const double rt = (double)(rel_humid * temp);  // float32 product, as typed in the reference
+    hi += -0.00000199 * (rt * rt);
+    if (rel_humid < 13.0f && 80.0f <= temp && temp <= 112.0f) {
+      hi -= ((13.0 - r) / 4.0) * __dsqrt_rn(fabs(17.0 - fabs(t - 95.0)) / 17.0);
+    } else if (rel_humid > 85.0f && 80.0f <= temp && temp <= 87.0f) {
+      hi += ((r - 85.0) / 10.0) * ((87.0 - t) / 5.0);
+    }
+  }
+  return (float)hi;
+}
+
+template <bool CELSIUS>
+__global__ __launch_bounds__(256) void heat_index_kernel(const float *__restrict__ temp,
+                                                         const float *__restrict__ rh, int64_t n,
+                                                         float *__restrict__ out) {
+  const int64_t n4 = n >> 2;
+  const float4 *t4 = reinterpret_cast<const float4 *>(temp);
+  const float4 *r4 = reinterpret_cast<const float4 *>(rh);
+  float4 *o4 = reinterpret_cast<float4 *>(out);
+  auto one = [](float t, float r) -> float {
+    if (CELSIUS) t = (t * 1.8f) + 32.0f;         // celsius_to_fahrenheit, float32 (measure.py:54)
+    float h = heat_index_f(t, r);
+    if (CELSIUS) h = (h - 32.0f) / 1.8f;          // fahrenheit_to_celsius, float32 (measure.py:37)
+    return h;
+  };
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n4; i += int64_t(gridDim.x) * blockDim.x) {
+    const float4 t = t4[i], r = r4[i];
+    o4[i] = make_float4(one(t.x, r.x), one(t.y, r.y), one(t.z, r.z), one(t.w, r.w));
+  }
+  for (int64_t i = (n4 << 2) + blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n;
+       i += int64_t(gridDim.x) * blockDim.x)
+    out[i] = one(temp[i], rh[i]);
+}
+
+int launch_heat_index(const float *temp_dev, const float *rh_dev, int64_t n, float *out_dev, bool celsius,
+                      hipStream_t stream) {
+  if (n == 0) return HDP_OK;
+  HDP_REQUIRE((reinterpret_cast<uintptr_t>(temp_dev) | reinterpret_cast<uintptr_t>(rh_dev) |
+               reinterpret_cast<uintptr_t>(out_dev)) % 16 == 0,
+              HDP_EINVAL, "heat index buffers must be 16-byte aligned");
+  int64_t g = ((n >> 2) + 255) / 256;
+  g = std::max<int64_t>(1, std::min<int64_t>(g, 256 * 16));
+  if (celsius)
+    hipLaunchKernelGGL(heat_index_kernel<true>, dim3((unsigned)g), dim3(256), 0, stream, temp_dev, rh_dev, n, out_dev);
+  else
+    hipLaunchKernelGGL(heat_index_kernel<false>, dim3((unsigned)g), dim3(256), 0, stream, temp_dev, rh_dev, n, out_dev);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
 }
 
 // ---- layout: time-major [T][n] (CMIP order) -> series-major [n][T] ---------------------------

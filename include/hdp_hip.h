@@ -166,6 +166,19 @@ int hdp_indicate_hot_days(const float *measure, int64_t n_series, int64_t T,
                           const double *thr, int64_t n_doy, const int64_t *doy_map,
                           uint8_t *hot);
 
+/* ---- heat index pre-step: replaces the ufunc heat_index (hdp/measure.py:61-94) ---------------
+ * NWS regression, element-wise: temp [deg F] f32, rel_humid [%] f32 -> heat index [deg F] f32.
+ * Arithmetic follows Numba's typing of the reference ufunc float32(float32, float32): float64
+ * throughout (its literals are float64) except the float32 product rel_humid*temp of the last
+ * polynomial term; the result is rounded to float32 once. */
+int hdp_heat_index_f32(const float *temp_f, const float *rel_humid, int64_t n, float *out);
+int hdp_heat_index_f32_dev(const float *temp_f_dev, const float *rel_humid_dev, int64_t n,
+                           float *out_dev, void *stream);
+/* Fused form of what format_standard_measures does around it (measure.py:185-189): Celsius in,
+ * Celsius out, with the reference's float32 conversions (t*1.8+32, (hi-32)/1.8) in between. */
+int hdp_heat_index_celsius_f32_dev(const float *temp_c_dev, const float *rel_humid_dev, int64_t n,
+                                   float *out_c_dev, void *stream);
+
 /* ---- synthetic inputs for bench.py (utils.py:61-78 formula) ---- */
 /* x_dev [n_cells][T]: 20 + 2 sin(2 pi (beta + t)/365) - 10|lat|/90 + noise + trend,
  * beta = 90 (south) / 270 (north), noise = u(seed,cell,t) * noise_scale,

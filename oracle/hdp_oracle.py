@@ -375,3 +375,47 @@ def compute_metrics_cells(x, thr, doy_map, defs, north, south, is_south) -> np.n
                 out[p, d, c, 2] = heatwave_duration(ids, seasons)
                 out[p, d, c, 3] = heatwave_average(ids, seasons).astype(np.int64)
     return out
+
+
+# --------------------------------------------------------------------------
+# heat index pre-step (hdp/measure.py:61-94) -- SURVEY.md 8(f) row 1
+# --------------------------------------------------------------------------
+
+def heat_index(temp, rel_humid) -> np.ndarray:
+    """measure.py:61-94 with Numba's typing of ``float32(float32, float32)``: the literals are
+    float64, so every operation promotes to float64 except ``rel_humid*temp`` (float32 * float32)
+    in the last polynomial term; the result is rounded to float32 once on return.  "parity
+    unpinned" at the ulp level (numba is not installable here); the stub-run of the reference
+    (NumPy scalar semantics, float32 throughout) agrees to ~1e-5 relative."""
+    t32 = np.asarray(temp, dtype=np.float32)
+    r32 = np.broadcast_to(np.asarray(rel_humid, dtype=np.float32), t32.shape)
+    t = t32.astype(np.float64)
+    r = r32.astype(np.float64)
+    simple = 0.5 * (t + 61.0 + ((t - 68.0) * 1.2) + (r * 0.094))
+    hi = np.full(t.shape, -42.379)
+    hi = hi + 2.04901523 * t
+    hi = hi + 10.14333127 * r
+    hi = hi + -0.22475541 * t * r
+    hi = hi + -0.00683783 * (t * t)
+    hi = hi + -0.05481717 * (r * r)
+    hi = hi + 0.00122874 * (t * t) * r
+    hi = hi + 0.00085282 * t * (r * r)
+    rt = (r32 * t32).astype(np.float64)                       # float32 product
+    hi = hi + -0.00000199 * (rt * rt)
+    dry = (r32 < 13) & (80 <= t32) & (t32 <= 112)
+    wet = (~dry) & (r32 > 85) & (80 <= t32) & (t32 <= 87)
+    with np.errstate(invalid="ignore"):
+        adj_dry = ((13 - r) / 4) * np.sqrt(np.abs(17 - np.abs(t - 95)) / 17)
+    adj_wet = ((r - 85) / 10) * ((87 - t) / 5)
+    hi = np.where(dry, hi - adj_dry, hi)
+    hi = np.where(wet, hi + adj_wet, hi)
+    return np.where(simple > 80, hi, simple).astype(np.float32)
+
+
+def heat_index_celsius(temp_c, rel_humid) -> np.ndarray:
+    """What format_standard_measures wraps around the ufunc (measure.py:185-189): float32
+    C -> F (measure.py:54), heat index, float32 F -> C (measure.py:37)."""
+    t = np.asarray(temp_c, dtype=np.float32)
+    tf = (t * np.float32(1.8)) + np.float32(32)
+    hi = heat_index(tf, rel_humid)
+    return (hi - np.float32(32)) / np.float32(1.8)

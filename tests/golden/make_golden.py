@@ -39,10 +39,17 @@ def install_stubs():
     nb.jit = ident
     nb.vectorize = ident
     nb.guvectorize = ident
-    nb.int64 = np.int64
-    nb.float64 = np.float64
-    nb.float32 = np.float32
-    nb.boolean = np.bool_
+    class _T:  # usable as a NumPy dtype (metric.py: dtype=nb.int64) and callable as a signature (measure.py:61)
+        def __init__(self, dt):
+            self.dtype = np.dtype(dt)
+
+        def __call__(self, *args):
+            return ("signature", self.dtype, args)
+
+    nb.int64 = _T(np.int64)
+    nb.float64 = _T(np.float64)
+    nb.float32 = _T(np.float32)
+    nb.boolean = _T(np.bool_)
     sys.modules["numba"] = nb
     xr = types.ModuleType("xarray")
     xr.DataArray = type("DataArray", (), {})
@@ -214,6 +221,22 @@ def main():
         out[f"{tag}_doy_map_head"] = ref_metric.build_doy_map(dates)[:400]
         out[f"{tag}_range"] = np.array([s, e])
     np.savez_compressed(os.path.join(HERE, "season_tables.npz"), **out)
+
+    # ---- (6) heat index: the reference ufunc body run as a scalar function ------
+    # Under the stubs the arithmetic is NumPy scalar float32 (weak Python-float promotion), not
+    # Numba's float64-with-float32-arguments typing: the fixture pins the formula and the branch
+    # structure to ~1e-5 relative, not the last bit.
+    import importlib
+    ref_measure = importlib.import_module("hdp.measure")
+    temps = np.linspace(40, 120, 81).astype(np.float32)
+    rhs = np.linspace(0, 100, 81).astype(np.float32)
+    tg, rg = np.meshgrid(temps, rhs, indexing="ij")
+    tt = np.concatenate([tg.ravel(), rng.uniform(60, 115, 400)]).astype(np.float32)
+    rr = np.concatenate([rg.ravel(), rng.uniform(0, 100, 400)]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        hi = np.array([ref_measure.heat_index(np.float32(a), np.float32(b)) for a, b in zip(tt, rr)],
+                      dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "heat_index.npz"), temp_f=tt, rel_humid=rr, reference_stub_run=hi)
     print("golden fixtures written to", HERE)
 
 

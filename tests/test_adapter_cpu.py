@@ -4,6 +4,7 @@ in hdp_amd.core are replaced by the oracle so only the Python plumbing is under 
 import numpy as np
 import pytest
 
+import hdp_amd._xr
 import hdp_amd.metric
 import hdp_amd.threshold
 from hdp_amd import calendar as cal
@@ -75,3 +76,29 @@ def test_compute_heatwave_metrics_single_series_signature(oracle_core):
     seasons = np.array([[120, 273], [485, 638]])
     got = hdp_amd.metric.compute_heatwave_metrics(x, thr, dm, 3, 1, 1, seasons)
     assert got.shape == (4, 2) and np.array_equal(got, orc.compute_heatwave_metrics(x, thr, dm, 3, 1, 1, seasons))
+
+
+def test_format_standard_measures_plumbing(monkeypatch):
+    """hdp.measure.format_standard_measures (measure.py:152-203) restated: float32, attrs, unit
+    conversion, one '<name>_hi' heat-index measure per temperature when rh is given (GPU call
+    replaced by the oracle here)."""
+    import hdp_amd.measure as measure
+    monkeypatch.setattr(core, "heat_index", lambda t, r: orc.heat_index(t, r))
+    base, lon, lat, dates = utils.generate_control_array(start_date="1700-01-01", end_date="1700-12-31")
+    xr = hdp_amd._xr.backend()
+    coords = {"lon": lon, "lat": lat, "time": dates}
+    temp_k = xr.DataArray(base + 273.15, dims=["lon", "lat", "time"], coords=coords, name="tas", attrs={"units": "K"})
+    rh = xr.DataArray(np.abs(base / base.max() - 0.3), dims=["lon", "lat", "time"], coords=coords, name="rh",
+                      attrs={"units": "g/g"})
+    ds = measure.format_standard_measures([temp_k], rh=rh)
+    assert sorted(ds.data_vars) == ["tas", "tas_hi"]
+    tas, hi = ds["tas"], ds["tas_hi"]
+    assert tas.dtype == np.float32 and tas.attrs["units"] == "degC" and tas.attrs["hdp_type"] == "measure"
+    assert tas.attrs["baseline_variable"] == "tas" and "Kelvin to Celsius" in tas.attrs["history"]
+    np.testing.assert_allclose(tas.values, base, atol=1e-4)
+    assert hi.dtype == np.float32 and hi.attrs["units"] == "degC" and hi.attrs["baseline_variable"] == "tas_hi"
+    want = orc.heat_index_celsius(tas.values, (rh.values.astype(np.float32) * np.float32(100)))
+    assert np.array_equal(hi.values, want)
+    with pytest.raises(AssertionError):
+        measure.format_standard_measures([xr.DataArray(base, dims=["lon", "lat", "time"], coords=coords, name="t",
+                                                       attrs={"units": "furlongs"})])

@@ -461,3 +461,17 @@ def test_c5_shaped_ensemble_thresholds_and_metrics():
     got = core.compute_heatwave_metrics(series, thr, dm, defs, north, south, hemi)
     want = c_oracle.metrics(series, np.concatenate([thr] * members), dm, defs, north, south, hemi)
     assert np.array_equal(got.astype(np.int64), want)
+
+
+# ---- heat index pre-step ----------------------------------------------------------
+
+def test_heat_index_matches_oracle_and_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "heat_index.npz"))
+    got = core.heat_index(g["temp_f"], g["rel_humid"])
+    assert got.dtype == np.float32
+    assert np.array_equal(got, orc.heat_index(g["temp_f"], g["rel_humid"]))          # bit-exact vs oracle
+    np.testing.assert_allclose(got.astype(np.float64), g["reference_stub_run"], rtol=1e-5, atol=1e-4)
+    rng = np.random.default_rng(0)
+    t = rng.uniform(-40, 130, size=100003).astype(np.float32)                         # odd size: tail path
+    r = rng.uniform(0, 100, size=100003).astype(np.float32)
+    assert np.array_equal(core.heat_index(t, r), orc.heat_index(t, r))

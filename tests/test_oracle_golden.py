@@ -143,3 +143,18 @@ def test_quantile_edge_cases():
     assert r[0] == 1.0 and np.isnan(r[2])
     with pytest.raises(ValueError):
         orc.numba_quantile([1.0, 2.0], [1.5])
+
+
+def test_heat_index_vs_reference_stub_run(golden_dir):
+    """SURVEY 8f row 1.  The fixture is the reference ufunc body run as a plain Python function on
+    NumPy float32 scalars; the oracle follows Numba's float64 typing of the same expression, so
+    the two agree to ~1e-5 relative, not bit for bit ("parity unpinned" at the ulp level)."""
+    g = np.load(os.path.join(golden_dir, "heat_index.npz"))
+    got = orc.heat_index(g["temp_f"], g["rel_humid"]).astype(np.float64)
+    ref = g["reference_stub_run"]
+    assert got.shape == ref.shape and got.size > 6000
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-4)
+    # every branch of the regression is exercised
+    t, r = g["temp_f"], g["rel_humid"]
+    assert ((ref <= 80).sum() > 100 and ((r < 13) & (t >= 80) & (t <= 112)).sum() > 50
+            and ((r > 85) & (t >= 80) & (t <= 87)).sum() > 20)

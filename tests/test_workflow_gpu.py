@@ -100,3 +100,47 @@ def test_time_major_and_member_inputs():
         for i, name in enumerate(("HWF", "HWN", "HWD", "HWA")):
             got = met[f"tas.tas_threshold.{name}"].values[:, :, m]
             assert np.array_equal(got.reshape(got.shape[:2] + (-1, got.shape[-1])), want[:, :, :, i, :])
+
+
+def test_full_data_workflow_with_relative_humidity():
+    """The reference's own workflow test shape (hdp/tests/test_workflow.py:15-61): temperature +
+    relative humidity -> format_standard_measures -> two measures (temp, temp_hi) -> thresholds for
+    both -> metrics for both pairs; plus numeric parity of the heat-index branch against the oracle."""
+    import hdp_amd.measure
+    from hdp_amd._xr import backend
+    xr = backend()
+    grid_shape = (2, 3)
+
+    def da(values, lon, lat, dates, name, units):
+        return xr.DataArray(values, dims=["lon", "lat", "time"], coords={"lon": lon, "lat": lat, "time": dates},
+                            name=name, attrs={"units": units})
+
+    base, lon, lat, bdates = utils.generate_control_array(grid_shape=grid_shape)
+    rh_vals = np.abs(base / base.max() - 0.3)                                  # utils.py:45-50
+    baseline_temp = da(base, lon, lat, bdates, "temp", "degC")
+    baseline_rh = da(rh_vals, lon, lat, bdates, "rh", "g/g")
+    baseline_measures = hdp_amd.measure.format_standard_measures([baseline_temp], rh=baseline_rh)
+    percentiles = np.arange(0.9, 1, 0.01)
+    thresholds = hdp_amd.threshold.compute_thresholds(baseline_measures, percentiles=percentiles)
+    warm, _, _, mdates = utils.generate_warming_array(grid_shape=grid_shape)
+    test_temp = da(warm, lon, lat, mdates, "temp", "degC")
+    test_rh = da(rh_vals, lon, lat, mdates, "rh", "g/g")
+    hw_definitions = [[3, 0, 0], [3, 1, 1], [4, 2, 0], [4, 1, 3], [5, 0, 1], [5, 1, 4]]
+    test_measures = hdp_amd.measure.format_standard_measures([test_temp], rh=test_rh)
+    metrics = hdp_amd.metric.compute_group_metrics(test_measures, thresholds, hw_definitions).compute()
+
+    assert (thresholds.percentile.values == percentiles).all()
+    assert len(thresholds.data_vars) == 2                                      # test_workflow.py:40
+    assert sorted(metrics.data_vars) == sorted(f"{m}.{m}_threshold.{k}" for m in ("temp", "temp_hi")
+                                               for k in ("HWF", "HWN", "HWD", "HWA"))
+    means = metrics.mean()
+    assert means["temp.temp_threshold.HWF"] >= means["temp.temp_threshold.HWD"] >= means["temp.temp_threshold.HWA"]
+    for var in metrics:
+        assert metrics[var].shape == (10, 6, 2, 3, 50) and metrics[var].dtype == int
+
+    # heat-index measure: bit-exact against the oracle's restatement of the same float32/float64 steps
+    want_hi = orc.heat_index_celsius(warm.astype(np.float32), (rh_vals.astype(np.float32) * np.float32(100)))
+    assert np.array_equal(test_measures["temp_hi"].values, want_hi)
+    x = baseline_measures["temp_hi"].values.reshape(-1, base.shape[-1])
+    want_thr = orc.compute_thresholds_cells(x, orc.datetimes_to_windows(bdates, 7), percentiles)
+    assert np.array_equal(thresholds["temp_hi_threshold"].values.reshape(want_thr.shape), want_thr)
