@@ -131,6 +131,7 @@ def main():
 
     import ctypes
     n_ev_steps = args.steps
+    mplan.reserve(bc)   # exceedance scratch allocated before anything is timed
     ev = [[[lib.hdp_event_create() for _ in range(3)] for _ in range(n_bands)] for _ in range(n_ev_steps)]
     t_thr, t_met = [], []
 

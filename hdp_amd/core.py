@@ -244,6 +244,10 @@ class MetricsPlan:
     def out_shape(self, n_cells):
         return (4, self.P, self.D, int(n_cells), self.year_pitch)
 
+    def reserve(self, n_cells):
+        """Allocate the exceedance scratch up front (keeps run() free of allocations)."""
+        _lib.check(self.lib.hdp_metrics_plan_reserve(self.handle, int(n_cells)))
+
     def run(self, x_ptr, thr_ptr, n_thr_cells, is_south_ptr, n_cells, out_ptr, stream=None):
         _lib.check(self.lib.hdp_metrics_f32_dev(self.handle, x_ptr, thr_ptr, int(n_thr_cells), is_south_ptr,
                                                 int(n_cells), out_ptr, stream))

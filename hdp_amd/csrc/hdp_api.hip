@@ -359,6 +359,12 @@ int hdp_metrics_plan_destroy(hdp_metrics_plan *plan) {
 
 int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan) { return plan ? plan->Ypitch : 0; }
 
+int hdp_metrics_plan_reserve(hdp_metrics_plan *plan, int64_t n_cells) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(plan && n_cells >= 0, HDP_EINVAL, "bad arguments");
+  return reserve_metrics_scratch(plan, n_cells);
+}
+
 int hdp_metrics_f32_dev(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
                         int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells,
                         int16_t *out_dev, void *stream) {

@@ -113,6 +113,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
 int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
                    int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells,
                    int16_t *out_dev, hipStream_t stream);
+int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells);
 int launch_table_percentiles(const float *x_dev, int64_t n_cells, int64_t T, const int64_t *win_dev,
                              int64_t n_doy, int64_t B, const QuantileParam *qp_dev,
                              const int32_t *klo_dev, const int32_t *khi_dev, int64_t P,

@@ -845,6 +845,29 @@ __global__ void generate_kernel(float *__restrict__ x, int64_t n_cells, int64_t 
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
+// series per launch pair of the split path (bounded scratch; multiples of n_thr_cells when
+// ensemble members share thresholds so that `c % n_thr_cells` stays valid inside a batch)
+int64_t metrics_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells, int64_t n_thr_cells) {
+  const int64_t words_pad = ((((plan->T + 63) >> 6) + kCW - 1) / kCW) * kCW;
+  const int64_t row_bytes = plan->P * words_pad * 8;
+  int64_t batch = std::max<int64_t>(1, (int64_t(4) << 30) / row_bytes);
+  if (const char *env = getenv("HDP_METRICS_BATCH")) batch = std::max<int64_t>(1, atoll(env));
+  if (n_thr_cells != n_cells && batch < n_cells)
+    batch = std::max<int64_t>(n_thr_cells, batch / n_thr_cells * n_thr_cells);
+  return std::min<int64_t>(batch, n_cells);
+}
+
+int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells) {
+  if (!plan->uniform_seasons || n_cells <= 0) return HDP_OK;
+  const int64_t words_pad = ((((plan->T + 63) >> 6) + kCW - 1) / kCW) * kCW;
+  const size_t need = size_t(metrics_batch_cells(plan, n_cells, n_cells)) * size_t(plan->P) * words_pad * 8;
+  if (plan->bits_scratch.bytes >= need) return HDP_OK;
+  hipError_t e = plan->bits_scratch.alloc(need);
+  if (e != hipSuccess)
+    return set_error(HDP_ENOMEM, "allocating %zu bytes of exceedance scratch failed: %s", need, hipGetErrorString(e));
+  return HDP_OK;
+}
+
 int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
                    int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells, int16_t *out_dev,
                    hipStream_t stream) {
@@ -894,11 +917,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   }
   // split path: exceedance words through an HBM scratch, in batches of series
   const size_t row_bytes = size_t(md.P) * md.words_pad * 8;
-  int64_t batch = std::max<int64_t>(1, (int64_t(4) << 30) / (int64_t)row_bytes);
-  if (const char *env = getenv("HDP_METRICS_BATCH")) batch = std::max<int64_t>(1, atoll(env));
-  if (n_thr_cells != n_cells && batch < n_cells)  // members share thresholds: keep c % n_thr_cells intact
-    batch = std::max<int64_t>(n_thr_cells, batch / n_thr_cells * n_thr_cells);
-  batch = std::min<int64_t>(batch, n_cells);
+  const int64_t batch = metrics_batch_cells(plan, n_cells, n_thr_cells);
   if (plan->bits_scratch.bytes < size_t(batch) * row_bytes) {
     HDP_HIP_TRY(hipStreamSynchronize(stream));  // the old scratch may still be in use
     hipError_t e = plan->bits_scratch.alloc(size_t(batch) * row_bytes);
