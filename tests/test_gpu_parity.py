@@ -475,3 +475,39 @@ def test_heat_index_matches_oracle_and_reference_fixture(golden_dir):
     t = rng.uniform(-40, 130, size=100003).astype(np.float32)                         # odd size: tail path
     r = rng.uniform(0, 100, size=100003).astype(np.float32)
     assert np.array_equal(core.heat_index(t, r), orc.heat_index(t, r))
+
+
+def test_tiny_and_degenerate_shapes():
+    """one cell / one percentile / one definition; a single year; a record too short for any
+    complete season (Y = 0: empty metrics, like the reference's empty 'year' axis)."""
+    rng = np.random.default_rng(99)
+    # one year, one cell, P = D = 1
+    dates = orc.noleap_date_range("2001-01-01", "2001-12-31")
+    x = rng.normal(size=(1, dates.size)).astype(np.float32)
+    ti, cols = cal.window_columns(dates, 7)
+    q = [0.9]
+    thr = core.compute_percentiles(x, ti, cols, q)
+    assert same_f64(thr, orc.compute_thresholds_cells(x, cal.expand_window_table(ti, cols), q))
+    dm = cal.build_doy_map(dates)
+    north, south, years = cal.hemisphere_season_tables(dates)
+    got = core.compute_heatwave_metrics(x, thr, dm, [[3, 0, 0]], north, south, np.zeros(1, np.uint8))
+    want = orc.compute_metrics_cells(x, thr, dm, [[3, 0, 0]], north, south, np.zeros(1, np.uint8))
+    assert got.shape == want.shape and np.array_equal(got.astype(np.int64), want)
+    # 100 days: no complete season.  The reference's trimming keeps the (-1, -1) row
+    # (metric.py:230-232) and then fails inside np.max on the empty slice; same error here.
+    short = orc.noleap_date_range("2001-01-01", "2001-04-10")
+    n2, s2, y2 = cal.hemisphere_season_tables(short)
+    n3, s3, _ = orc.hemisphere_ranges(short)
+    assert np.array_equal(n2, n3) and np.array_equal(s2, s3) and (n2 == -1).all()
+    xs = rng.normal(size=(2, short.size)).astype(np.float32)
+    with pytest.raises(ValueError, match="zero-size array"):
+        core.compute_heatwave_metrics(xs, np.zeros((2, 365, 1)), cal.build_doy_map(short), [[3, 0, 0]], n2, s2,
+                                      np.zeros(2, np.uint8))
+    # an empty season table is accepted and yields an empty year axis
+    empty = np.zeros((0, 2), dtype=np.int64)
+    out = core.compute_heatwave_metrics(xs, np.zeros((2, 365, 1)), cal.build_doy_map(short), [[3, 0, 0]], empty,
+                                        empty, np.zeros(2, np.uint8))
+    assert out.shape == (1, 1, 2, 4, 0)
+    # window radius larger than the record's day-of-year count is an IndexError in the reference too
+    with pytest.raises(IndexError):
+        cal.window_columns(orc.noleap_date_range("2001-01-01", "2001-01-05"), 7)
