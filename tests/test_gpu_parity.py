@@ -511,3 +511,25 @@ def test_tiny_and_degenerate_shapes():
     # window radius larger than the record's day-of-year count is an IndexError in the reference too
     with pytest.raises(IndexError):
         cal.window_columns(orc.noleap_date_range("2001-01-01", "2001-01-05"), 7)
+
+
+def test_thresholds_extreme_magnitudes_and_subnormals():
+    """float32 subnormals, +-FLT_MAX-scale values, signed zeros and mixed signs survive the
+    key transform, the med3-based sort and the integer merge unchanged."""
+    rng = np.random.default_rng(404)
+    dates = orc.noleap_date_range("2001-01-01", "2008-12-31")
+    T = dates.size
+    x = np.empty((5, T), dtype=np.float32)
+    x[0] = (rng.integers(-2000, 2000, size=T) * np.float32(1e-42)).astype(np.float32)   # subnormals of both signs
+    x[1] = rng.choice(np.array([3.0e38, -3.0e38, 1.0, -1.0, 0.0, -0.0], dtype=np.float32), size=T)
+    x[2] = rng.normal(0, 1e-30, size=T).astype(np.float32)
+    x[3] = np.where(rng.random(T) < 0.5, np.float32(0.0), np.float32(-0.0))
+    x[4] = rng.normal(-250.0, 40.0, size=T).astype(np.float32)                          # all negative
+    assert np.any((np.abs(x[0]) > 0) & (np.abs(x[0]) < 1.2e-38))
+    ti, cols = cal.window_columns(dates, 7)
+    q = [0.0, 0.05, 0.5, 0.9, 0.99, 1.0]
+    with np.errstate(all="ignore"):
+        want = orc.compute_thresholds_cells(x, cal.expand_window_table(ti, cols), q)
+    got = core.compute_percentiles(x, ti, cols, q)
+    assert same_f64(got, want)
+    assert same_f64(core.compute_percentiles_table(x, cal.expand_window_table(ti, cols), q), want)
