@@ -428,7 +428,6 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
   const int max_break = md.defs[my_d * 3 + 1];
   const int max_subs = md.defs[my_d * 3 + 2];
   const int dmax = md.dmax;
-  const int Ypitch_unused = md.Ypitch; (void)Ypitch_unused;
   const int64_t row = ((int64_t(my_p) * md.D + my_d) * md.out_cells + md.cell_off + cell) * md.Ypitch;
   const int64_t plane = int64_t(md.P) * md.D * md.out_cells * md.Ypitch;
   int16_t *orow = out + row;
