@@ -184,7 +184,6 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_general(
   for (int w0 = 0; w0 < n_words; w0 += kChunkWords) {
     const int nw = min(kChunkWords, n_words - w0);
     // ---- stage A: exceedance words for this chunk --------------------------------------
-#pragma unroll 4
     for (int w = 0; w < nw; ++w) {
       const int t = (w0 + w) * 64 + lane;
       const bool in = t < md.T;
