@@ -40,7 +40,7 @@ struct ThrDev {
   unsigned long long *clk;  // [4] accumulated s_memtime ticks of wave 0: load, sort, merge, blocks (debug & 8)
 };
 
-constexpr int kThrThreads = 256;
+constexpr int kThrThreads = 512;  // 8 waves: all of them load and sort, ceil(rows/64) of them merge
 
 __device__ __forceinline__ float f32_nan() { return __int_as_float(0x7fc00000); }
 
@@ -508,7 +508,8 @@ __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf
 }
 
 template <int EPL>
-__global__ __launch_bounds__(kThrThreads) void thresholds_kernel(ThrDev pd, const float *__restrict__ x,
+// second bound: 4 waves per SIMD = two 512-thread workgroups per CU (<= 128 VGPRs)
+__global__ __launch_bounds__(kThrThreads, 4) void thresholds_kernel(ThrDev pd, const float *__restrict__ x,
                                                                  int64_t n_cells,
                                                                  double *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -897,12 +898,10 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
       }
       return 0;
     };
-    // prefer 3 workgroups per CU, then 2, then whatever fits one CU
-    int r = fit(52 * 1024);
-    if (r < std::min<int64_t>(n_doy, 32)) {
-      r = fit(78 * 1024);
-      if (r < std::min<int64_t>(n_doy, 16)) r = fit(kMaxLds);
-    }
+    // two 512-thread workgroups per CU (<= 78 KB each), else whatever fits one CU; measured at C3:
+    // 122-row blocks with two merging waves beat 61-row blocks (fewer halo columns per row)
+    int r = fit(78 * 1024);
+    if (r < std::min<int64_t>(n_doy, 16)) r = fit(kMaxLds);
     if (r > 0) {
       const int nb = int((n_doy + r - 1) / r);
       rows = int((n_doy + nb - 1) / nb);  // balance the blocks
