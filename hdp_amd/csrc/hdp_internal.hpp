@@ -92,6 +92,14 @@ struct hdp_threshold_plan {
   hdp::DevBuf cols_local;  // uint16 [n_doy][W] local column of each window member
   hdp::DevBuf qparam;      // QuantileParam [P]
   hdp::DevBuf tgt_top, tgt_bot;  // int2 (rank, slot) sorted by rank
+  // pipelined kernel (S <= 128): producer waves gather + sort the next block in registers while
+  // the merging waves work on the current one
+  bool pipe = false;
+  int32_t lpc = 0;          // lanes per column of the register sort (1..16), 8 keys per lane
+  int32_t n_merge = 0;      // waves that merge (ceil(rows_per_block / 64)); the rest produce
+  hdp::DevBuf tix;          // int32 [n_doy][8 * lpc] time index of sample e of a day-of-year column, -1 = none
+  hdp::DevBuf blk_col_off;  // int32 [n_blocks] offset into col_doy
+  hdp::DevBuf col_doy;      // int32 day-of-year row of each block-local column
   mutable hdp::DevBuf clk;       // HDP_THR_DEBUG=8 phase clocks
 };
 

@@ -34,6 +34,8 @@ struct ThrDev {
   const uint16_t *cols_local;
   const QuantileParam *qp;
   const int2 *tgt_top, *tgt_bot;
+  const int32_t *tix, *blk_col_off, *col_doy;  // pipelined kernel: (column, sample) -> time index
+  int SL, n_merge;                             // pitch of tix (8 * lanes per column); merging waves
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
   int debug;  // timing ablations only (HDP_THR_DEBUG): 1 = no merge, 2 = no sort, 4 = no load, 8 = phase clocks
@@ -321,8 +323,7 @@ __device__ __forceinline__ void group_winner(const int4 &h, const uint4 &q, int 
 // what to do when the merge reaches a requested rank (host-built list, sorted by rank)
 enum EmitKind : int { E_TOP_PAIR = 0, E_BOT_PAIR = 1, E_SAME = 2, E_MAX = 3, E_MIN = 4 };
 
-struct RowFlags {  // NaN / infinity census of the row's window (numba's special cases)
-  bool has_nan;
+struct RowFlags {  // NaN / infinity census of the row's window (numba's special cases); n_pos < 0: a NaN is present
   int n_pos, n_neg;
 };
 
@@ -338,7 +339,7 @@ __device__ __forceinline__ void emit_targets(const ThrDev &pd, const int2 *tgt, 
     float lo = key_f32(best), hi = key_f32(best);
     if (kind == E_TOP_PAIR) hi = key_f32(prev);
     if (kind == E_BOT_PAIR) lo = key_f32(prev);
-    if (store) orow[p] = finish_quantile(pd.qp[p], lo, hi, rf.has_nan, rf.n_pos, rf.n_neg, pd.n);
+    if (store) orow[p] = finish_quantile(pd.qp[p], lo, hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
     ++k;
   } while (k < nt && tgt[k].x == step);
   next_rank = k < nt ? tgt[k].x : -1;
@@ -486,23 +487,25 @@ __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf
 #pragma unroll
     for (int j = 0; j < 4 * NG; ++j) clr[j] = (j < pd.W) ? int(cl[j]) : 0;
   }
-  RowFlags rf{false, 0, 0};
+  RowFlags rf{0, 0};
+  uint32_t nan_or = 0;
   if constexpr (NG > 0) {
 #pragma unroll
     for (int j = 0; j < 4 * NG; ++j) {
       const uint32_t f = (j < pd.W) ? flags[clr[j]] : 0u;
-      rf.has_nan |= (f >> 31) != 0;
+      nan_or |= f;
       rf.n_pos += (f >> 15) & 0x7fff;
       rf.n_neg += f & 0x7fff;
     }
   } else {
     for (int j = 0; j < pd.W; ++j) {
       const uint32_t f = flags[cl[j]];
-      rf.has_nan |= (f >> 31) != 0;
+      nan_or |= f;
       rf.n_pos += (f >> 15) & 0x7fff;
       rf.n_neg += f & 0x7fff;
     }
   }
+  if (nan_or >> 31) rf.n_pos = -1;
   merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, clr, r, rf, store, orow);
   merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, clr, r, rf, store, orow);
 }
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_kernel(ThrDev pd, c
   float *colbuf = reinterpret_cast<float *>(smem + off);
   off += (size_t(pd.ncols_max) * pd.S_pad * 4 + 15) & ~size_t(15);
   uint32_t *flags = reinterpret_cast<uint32_t *>(smem + off);
-  off += (size_t(pd.ncols_max) * 4 + 15) & ~size_t(15);
+  off += 2 * ((size_t(pd.ncols_max) * 4 + 15) & ~size_t(15));  // second copy: pipelined kernel only
   float *hbuf = reinterpret_cast<float *>(smem + off);
   off += size_t(pd.Wp) * pd.RP * 4;
   uint32_t *posb = reinterpret_cast<uint32_t *>(smem + off);
@@ -603,6 +606,205 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_kernel(ThrDev pd, c
       atomicAdd(&pd.clk[1], t_c - t_b);
       atomicAdd(&pd.clk[2], t_d - t_c);
       atomicAdd(&pd.clk[3], 1ull);
+    }
+  }
+}
+
+// ---- pipelined form (S <= 128): the workgroup's waves are specialised --------------------------
+// The merge is a latency-bound dependent chain that only ceil(rows/64) waves can work on, while
+// load + sort need no LDS at all when the sort runs in registers.  So waves [0, n_merge) merge block
+// k out of the LDS image while waves [n_merge, 8) gather block k+1 straight from HBM into the
+// register layout of the DPP-row sorter, sort it there and hold the keys until the image is free.
+// The workgroup is persistent (it walks cells blockIdx.x, blockIdx.x + gridDim.x, ...) so the
+// pipeline also runs across cell boundaries.  Two barriers per block: "image free / keys ready" and
+// "image written".  Results are identical to thresholds_kernel (same sort network, same merge).
+constexpr int kHold = 6;  // column groups a producer wave holds per block (8 VGPRs each)
+
+template <int LPC>
+__global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev pd, const float *__restrict__ x,
+                                                                      int64_t n_cells,
+                                                                      double *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int nwaves = kThrThreads / 64;
+  constexpr int kCols = 64 / LPC;
+
+  size_t off = 0;
+  float *colbuf = reinterpret_cast<float *>(smem + off);
+  off += (size_t(pd.ncols_max) * pd.S_pad * 4 + 15) & ~size_t(15);
+  uint32_t *flags0 = reinterpret_cast<uint32_t *>(smem + off);  // census words, double-buffered by block parity
+  const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
+  off += 2 * size_t(flags_pitch) * 4;
+  float *hbuf = reinterpret_cast<float *>(smem + off);
+  off += size_t(pd.Wp) * pd.RP * 4;
+  uint32_t *posb = reinterpret_cast<uint32_t *>(smem + off);
+
+  // Roles.  The merge is a dependent chain that issues about one instruction per 8 cycles, so two
+  // merging waves on one SIMD slow each other down (measured: +36 %) while a SIMD without any is
+  // wasted.  Waves therefore take roles by the SIMD they landed on (HW_ID.SIMD_ID): one merging wave
+  // per SIMD first, starting at SIMD 2*(thread-group slot & 1) so that the two workgroups resident on
+  // a CU use different SIMDs.  The assignment only steers performance; any outcome is correct.
+  const int n_merge = pd.n_merge;
+  const int n_prod = nwaves - n_merge;
+  __shared__ int s_simd[nwaves];
+  uint32_t hwid;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+  const int my_simd = (pd.debug & 64) ? (wave & 3) : int((hwid >> 4) & 3u);
+  const int tg_par = (pd.debug & 64) ? 0 : int((hwid >> 16) & 1u);
+  if (lane == 0) s_simd[wave] = my_simd;
+  __syncthreads();
+  int rank = 0;
+  {
+    // order: (how many lower-numbered waves share my SIMD, SIMD distance from the preferred one, wave)
+    int occ_me = 0;
+    for (int w = 0; w < wave; ++w) occ_me += (s_simd[w] == my_simd);
+    const int key_me = (occ_me * 4 + ((my_simd - 2 * tg_par) & 3)) * nwaves + wave;
+    for (int w = 0; w < nwaves; ++w) {
+      const int sw = s_simd[w];
+      int occ = 0;
+      for (int u = 0; u < w; ++u) occ += (s_simd[u] == sw);
+      const int key = (occ * 4 + ((sw - 2 * tg_par) & 3)) * nwaves + w;
+      rank += (key < key_me);
+    }
+  }
+  rank = __builtin_amdgcn_readfirstlane(rank);
+  const bool producer = rank >= n_merge;  // wave-uniform
+  const int pw = rank - n_merge;           // producer index
+  const int mrow = rank * 64 + lane;       // merging waves: row of the block this lane merges
+
+  const int64_t my_cells = (n_cells - int64_t(blockIdx.x) + gridDim.x - 1) / gridDim.x;
+  const int64_t n_items = my_cells * pd.n_blocks;  // (cell, block) pairs of this workgroup
+
+  for (int64_t s = 0; s <= n_items; ++s) {
+    // sorted keys + census of this producer wave's column groups; defined and consumed inside one
+    // iteration, on the producer path only, so the merging waves' registers are not charged for them
+    float hold[kHold][8];
+    uint32_t *flags_p = flags0 + int(s & 1) * flags_pitch;        // census of block s (being produced)
+    const uint32_t *flags_m = flags0 + int((s + 1) & 1) * flags_pitch;  // census of block s - 1 (being merged)
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;  // debug & 32: phase clocks
+    const bool clocked = (pd.debug & 32) && lane == 0 && (rank == 0 || rank == n_merge);
+    if (clocked) c0 = c1 = __builtin_readcyclecounter();
+    const int64_t cell_p = int64_t(blockIdx.x) + (s / pd.n_blocks) * gridDim.x;
+    const int blk_p = int(s % pd.n_blocks);
+    if (producer) {
+      if (s < n_items) {
+        // ---- gather + sort block `s` in registers ------------------------------------------------
+        const float *xc = x + cell_p * int64_t(pd.T);
+        const int ncols = pd.blk_ncols[blk_p];
+        const int32_t *cd = pd.col_doy + pd.blk_col_off[blk_p];
+        // lane coordinates re-materialised here: anything derived from them stays inside the producer
+        // branch instead of being hoisted into registers that would be live across the merge
+        int grp = lane / LPC, l = lane % LPC;
+        asm volatile("" : "+v"(grp), "+v"(l));
+#pragma unroll
+        for (int j = 0; j < kHold; ++j) {
+          const int c0 = (pw + j * n_prod) * kCols;
+          if (c0 < ncols) {  // wave-uniform
+            const int lc = c0 + grp;
+            const bool active = lc < ncols;
+            const int doy = cd[active ? lc : c0];
+            const int4 *tp = reinterpret_cast<const int4 *>(pd.tix + size_t(doy) * pd.SL + l * 8);
+            const int4 ta = tp[0], tb = tp[1];
+            const int t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              hold[j][i] = (active && t[i] >= 0 && !(pd.debug & 4)) ? xc[t[i]] : -INFINITY;
+          }
+        }
+        if (clocked) c1 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int j = 0; j < kHold; ++j) {
+          const int c0 = (pw + j * n_prod) * kCols;
+          if (c0 < ncols) {
+            const bool active = (c0 + grp) < ncols;
+            uint32_t cnt = 0;  // nan << 20 | +inf << 10 | -inf
+            bool special = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const bool real = active && (l * 8 + i) < pd.S;
+              special |= real && ((__float_as_uint(hold[j][i]) & 0x7f800000u) == 0x7f800000u);
+            }
+            if (__ballot(special) != 0) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const bool real = active && (l * 8 + i) < pd.S;
+                float v = hold[j][i];
+                if (v != v) { cnt += 1u << 20; v = 0.0f; }
+                if (real && v == INFINITY) cnt += 1u << 10;
+                if (real && v == -INFINITY) cnt += 1u;
+                hold[j][i] = v;
+              }
+            }
+            if (!(pd.debug & 2)) sort_group_desc<LPC>(hold[j], l);
+            if constexpr (LPC >= 2) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor1, 0xf, 0xf, false);
+            if constexpr (LPC >= 4) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor2, 0xf, 0xf, false);
+            if constexpr (LPC >= 8) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppHalfMirror, 0xf, 0xf, false);
+            if constexpr (LPC >= 16) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppMirror, 0xf, 0xf, false);
+            if (active && l == 0)
+              flags_p[c0 + grp] = ((cnt >> 20) ? 0x80000000u : 0u) | (((cnt >> 10) & 0x3ffu) << 15) | (cnt & 0x3ffu);
+          }
+        }
+      }
+    } else if (s >= 1) {
+      // ---- merge block `s - 1` out of the LDS image ----------------------------------------------
+      const int64_t sm = s - 1;
+      const int64_t cell = int64_t(blockIdx.x) + (sm / pd.n_blocks) * gridDim.x;
+      const int b = int(sm % pd.n_blocks);
+      const int row0 = pd.blk_row0[b];
+      const int nrows = pd.blk_nrows[b];
+      if (mrow < nrows && !(pd.debug & 1)) {
+        const int row = row0 + mrow;
+        const uint16_t *cl = pd.cols_local + size_t(row) * pd.W;
+        double *orow = out + (cell * pd.n_doy + row) * int64_t(pd.P);
+        switch (pd.Wp >> 2) {
+          case 1: merge_both<1>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow); break;
+          case 2: merge_both<2>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow); break;
+          case 4: merge_both<4>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow); break;
+          default: merge_both<0>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow); break;
+        }
+      }
+    }
+    if (clocked) c2 = __builtin_readcyclecounter();
+    __syncthreads();  // image free (merge s-1 done), keys of block s sorted
+    if (clocked) c3 = __builtin_readcyclecounter();
+    if (producer && s < n_items) {
+      const int ncols = pd.blk_ncols[blk_p];
+      int grp = lane / LPC, l = lane % LPC;
+      asm volatile("" : "+v"(grp), "+v"(l));
+#pragma unroll
+      for (int j = 0; j < kHold; ++j) {
+        const int lc = (pw + j * n_prod) * kCols + grp;
+        if (lc < ncols) {
+          float *col = colbuf + lc * pd.S_pad + 1;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int e = l * 8 + i;
+            if (e < pd.S) col[e] = __int_as_float(f32_key(hold[j][i]));
+          }
+          if (l == 0) {
+            col[-1] = __int_as_float(kKeyMax);     // below every ascending walk
+            col[pd.S] = __int_as_float(kKeyMin);   // below every descending walk
+          }
+        }
+      }
+    }
+    if (clocked) c4 = __builtin_readcyclecounter();
+    __syncthreads();  // image of block s ready
+    if (clocked) {
+      c5 = __builtin_readcyclecounter();
+      if (rank == 0) {  // merging wave: work, wait for the producers, wait for the image
+        atomicAdd(&pd.clk[0], c2 - c0);
+        atomicAdd(&pd.clk[1], c3 - c2);
+        atomicAdd(&pd.clk[2], c5 - c3);
+        atomicAdd(&pd.clk[3], 1ull);
+      } else {  // first producer wave: gather issue, sort (+ load wait), wait for the merge, write, barrier
+        atomicAdd(&pd.clk[4], c1 - c0);
+        atomicAdd(&pd.clk[5], c2 - c1);
+        atomicAdd(&pd.clk[6], c3 - c2);
+        atomicAdd(&pd.clk[7], c4 - c3);
+      }
     }
   }
 }
@@ -708,6 +910,30 @@ static int launch_thr_epl(const ThrDev &pd, size_t lds, const float *x, int64_t 
   return HDP_OK;
 }
 
+template <int LPC>
+static int launch_thr_pipe(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
+                           hipStream_t stream) {
+  auto kern = thresholds_pipe_kernel<LPC>;
+  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // persistent workgroups: as many as the device keeps resident, each walking a strided set of cells
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    HDP_HIP_TRY(hipGetDevice(&dev));
+    HDP_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  int per_cu = 0;
+  HDP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern),
+                                                           kThrThreads, lds));
+  if (per_cu < 1) per_cu = 1;
+  int64_t grid = std::min<int64_t>(n_cells, int64_t(per_cu) * n_cu);
+  if (const char *env = getenv("HDP_THR_GRID")) grid = std::max<int64_t>(1, std::min<int64_t>(n_cells, atoll(env)));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThrThreads), lds, stream, pd, x, n_cells, out);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
 int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_t n_cells,
                       double *out_dev, hipStream_t stream) {
   if (n_cells == 0) return HDP_OK;
@@ -739,14 +965,29 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.nt_top = plan->nt_top;
   pd.nt_bot = plan->nt_bot;
   pd.n = (int)plan->n;
+  pd.tix = plan->tix.as<int32_t>();
+  pd.blk_col_off = plan->blk_col_off.as<int32_t>();
+  pd.col_doy = plan->col_doy.as<int32_t>();
+  pd.SL = 8 * plan->lpc;
+  pd.n_merge = plan->n_merge;
   pd.debug = getenv("HDP_THR_DEBUG") ? atoi(getenv("HDP_THR_DEBUG")) : 0;
   pd.clk = nullptr;
-  if (pd.debug & 8) {
+  if (pd.debug & (8 | 32)) {
     if (plan->clk.bytes == 0) {
-      HDP_HIP_TRY(plan->clk.alloc(4 * sizeof(unsigned long long)));
-      HDP_HIP_TRY(hipMemset(plan->clk.p, 0, 4 * sizeof(unsigned long long)));
+      HDP_HIP_TRY(plan->clk.alloc(8 * sizeof(unsigned long long)));
+      HDP_HIP_TRY(hipMemset(plan->clk.p, 0, 8 * sizeof(unsigned long long)));
     }
     pd.clk = plan->clk.as<unsigned long long>();
+  }
+  const char *pipe_env = getenv("HDP_THR_PIPE");
+  if (plan->pipe && !(pipe_env && atoi(pipe_env) == 0) && !(pd.debug & 8)) {
+    switch (plan->lpc) {
+      case 1: return launch_thr_pipe<1>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 2: return launch_thr_pipe<2>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 4: return launch_thr_pipe<4>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 8: return launch_thr_pipe<8>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      default: return launch_thr_pipe<16>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+    }
   }
   switch (plan->epl) {
     case 1: return launch_thr_epl<1>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
@@ -858,7 +1099,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   auto lds_for = [&](int rows, int ncols) -> size_t {
     const int RP = (rows + 63) & ~63;
     size_t b = (size_t(ncols) * spad * 4 + 15) & ~size_t(15);
-    b += (size_t(ncols) * 4 + 15) & ~size_t(15);
+    b += 2 * ((size_t(ncols) * 4 + 15) & ~size_t(15));  // census words (x2: pipelined kernel)
     b += size_t(pl->Wp) * RP * 4;       // heads
     b += size_t(pl->Wp) * RP * 4;       // position | slot payloads
     return b;
@@ -907,6 +1148,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
       rows = int((n_doy + nb - 1) / nb);  // balance the blocks
     }
   }
+  const bool rows_forced = getenv("HDP_THR_ROWS") != nullptr;
   rows = (int)std::min<int64_t>(rows, std::min<int64_t>(n_doy, hdp::kThrThreads));
   int cm = 0;
   if (rows <= 0 || max_lds_for_rows(rows, &cm) > kMaxLds) {
@@ -914,6 +1156,35 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     return set_error(HDP_EUNSUP, "window of %lld x %lld samples does not fit the 160 KiB LDS",
                      (long long)W, (long long)S);
   }
+  // pipelined kernel (register sort, S <= 128): at most 6 merging waves, and every producer wave must
+  // be able to hold its share of the block's column groups; shrink the block if that is all it takes
+  int lpc = 0;
+  if (S <= 128) {
+    lpc = 1;
+    while (8 * lpc < S) lpc <<= 1;
+  }
+  auto pipe_ok = [&](int r, int ncols_max) -> bool {
+    if (!lpc) return false;
+    const int nm = (r + 63) / 64, np = hdp::kThrThreads / 64 - nm;
+    if (np < 2) return false;
+    const int kc = 64 / lpc, ng = (ncols_max + kc - 1) / kc;
+    return (ng + np - 1) / np <= hdp::kHold;
+  };
+  bool pipe = pipe_ok(rows, cm);
+  if (lpc && !pipe && !rows_forced) {
+    for (int r = rows - 1; r >= std::max(1, rows / 2); --r) {
+      const int nb = int((n_doy + r - 1) / r);
+      const int rb = int((n_doy + nb - 1) / nb);
+      int c2 = 0;
+      if (max_lds_for_rows(rb, &c2) <= kMaxLds && pipe_ok(rb, c2)) {
+        rows = rb; cm = c2; pipe = true;
+        break;
+      }
+    }
+  }
+  pl->pipe = pipe;
+  pl->lpc = lpc;
+  pl->n_merge = (rows + 63) / 64;
   pl->rows_per_block = rows;
   pl->RP = (rows + 63) & ~63;
   pl->ncols_max = cm;
@@ -921,7 +1192,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   pl->n_blocks = int((n_doy + rows - 1) / rows);
 
   // per-block tables
-  std::vector<int32_t> row0s, nrows, ncols, loff, llen;
+  std::vector<int32_t> row0s, nrows, ncols, loff, llen, coff, cdoy;
   std::vector<int2> list;
   std::vector<uint16_t> cl(size_t(n_doy) * W);
   std::vector<int> set, local(n_doy);
@@ -941,6 +1212,8 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
         list.push_back(make_int2((int)t, int(i) * spad + 1 + (int)s));
       }
     std::stable_sort(list.begin() + start, list.end(), [](const int2 &a, const int2 &b) { return a.x < b.x; });
+    coff.push_back((int)cdoy.size());
+    for (size_t i = 0; i < set.size(); ++i) cdoy.push_back(set[i]);
     row0s.push_back(r0);
     nrows.push_back(nr);
     ncols.push_back((int)set.size());
@@ -965,6 +1238,19 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   up(pl->qparam, qp.data(), qp.size() * sizeof(hdp::QuantileParam));
   up(pl->tgt_top, ttop.data(), ttop.size() * sizeof(int2));
   up(pl->tgt_bot, tbot.data(), tbot.size() * sizeof(int2));
+  if (lpc) {
+    const int SL = 8 * lpc;
+    std::vector<int32_t> tix(size_t(n_doy) * SL, -1);
+    for (int64_t d = 0; d < n_doy; ++d)
+      for (int64_t e = 0; e < S; ++e) {
+        int64_t t = time_index[d * S + e];
+        if (t < 0) t += T;
+        tix[size_t(d) * SL + e] = (int32_t)t;
+      }
+    up(pl->tix, tix.data(), tix.size() * 4);
+    up(pl->blk_col_off, coff.data(), coff.size() * 4);
+    up(pl->col_doy, cdoy.data(), cdoy.size() * 4);
+  }
   if (e != hipSuccess) {
     delete pl;
     return set_error(HDP_EHIP, "uploading threshold plan tables failed: %s", hipGetErrorString(e));
@@ -975,8 +1261,14 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
 
 extern "C" int hdp_threshold_plan_destroy(hdp_threshold_plan *plan) {
   if (plan && plan->clk.bytes) {  // HDP_THR_DEBUG=8: per-phase clocks of the lead wave, summed over blocks
-    unsigned long long c[4] = {0, 0, 0, 0};
-    if (hipMemcpy(c, plan->clk.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && c[3])
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpy(c, plan->clk.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && c[3] && (c[4] | c[5]))
+      fprintf(stderr,
+              "[hdp thresholds pipe] items=%llu  ticks/item: merge=%.0f wait_producers=%.0f wait_image=%.0f | "
+              "producer: gather=%.0f sort=%.0f wait_merge=%.0f write=%.0f\n",
+              c[3], double(c[0]) / c[3], double(c[1]) / c[3], double(c[2]) / c[3], double(c[4]) / c[3],
+              double(c[5]) / c[3], double(c[6]) / c[3], double(c[7]) / c[3]);
+    else if (c[3])
       fprintf(stderr, "[hdp thresholds] blocks=%llu  ticks/block: load=%.0f sort=%.0f merge=%.0f\n", c[3],
               double(c[0]) / c[3], double(c[1]) / c[3], double(c[2]) / c[3]);
   }
