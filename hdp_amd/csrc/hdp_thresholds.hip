@@ -346,13 +346,55 @@ __device__ __forceinline__ void emit_targets(const ThrDev &pd, const int2 *tgt, 
 }
 
 // ---- W-way merge, one lane per day-of-year row ------------------------------------------------
-// Heads (keys) and payloads ((LDS position << 8) | head slot) live in a lane-private LDS strip
-// [group of 4][row][4].  The winner of every group is cached in registers; a step
-//   1. takes the best cached group winner (NG-1 max + selects),
-//   2. issues, together, the read of the winner column's next key and of the winner's group,
-//   3. patches the group in registers, recomputes that one group winner, writes the new head back.
-// One LDS round trip per step, no full rescan of the W heads.  NG = ceil(W/4) is a template
-// parameter (NG = 0: generic rescan loop for very wide windows).
+// Heads (keys) and payloads live in a lane-private LDS strip [group of 4][row][4]; within a group the
+// heads are kept sorted best-first, and the group tops are cached, also sorted, in registers.  A step
+//   1. pops the best cached top m[0] (payload = LDS position << 2 | group),
+//   2. issues, together, the read of that column's next key and of the winner's group,
+//   3. bubbles the new key into the group (three levels), writes the group back,
+//   4. bubbles the group's new top into the cached tops.
+// One LDS round trip and about 45 issue slots per step; only the first level of each bubble is on the
+// step-to-step critical path.  NG = ceil(W/4) is a template parameter (NG = 0: generic rescan loop
+// for very wide windows, payload = position << 8 | slot).
+template <bool TOP>
+__device__ __forceinline__ int kworst(int a, int b) { return TOP ? min(a, b) : max(a, b); }
+
+// compare-exchange of (key, payload) pairs: the better key ends up in a
+template <bool TOP>
+__device__ __forceinline__ void ce_kp(int &ka, uint32_t &pa, int &kb, uint32_t &pb) {
+  const bool swap = TOP ? (ka < kb) : (ka > kb);
+  const int hi = kbest<TOP>(ka, kb), lo = kworst<TOP>(ka, kb);
+  const uint32_t ph = swap ? pb : pa, pl = swap ? pa : pb;
+  ka = hi; kb = lo; pa = ph; pb = pl;
+}
+
+// k[1..N) is sorted best-first; k[0] is new: bubble it down to its place
+template <bool TOP, int N>
+__device__ __forceinline__ void insert_front(int (&k)[N], uint32_t (&p)[N]) {
+#pragma unroll
+  for (int i = 0; i + 1 < N; ++i) ce_kp<TOP>(k[i], p[i], k[i + 1], p[i + 1]);
+}
+
+template <bool TOP>
+__device__ __forceinline__ void sort4_best_first(int (&k)[4], uint32_t (&p)[4]) {
+  ce_kp<TOP>(k[0], p[0], k[1], p[1]);
+  ce_kp<TOP>(k[2], p[2], k[3], p[3]);
+  ce_kp<TOP>(k[0], p[0], k[2], p[2]);
+  ce_kp<TOP>(k[1], p[1], k[3], p[3]);
+  ce_kp<TOP>(k[1], p[1], k[2], p[2]);
+}
+
+template <bool TOP, int N>
+__device__ __forceinline__ void sort_best_first(int (&k)[N], uint32_t (&p)[N]) {
+  if constexpr (N == 4) {
+    sort4_best_first<TOP>(k, p);
+  } else {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+#pragma unroll
+      for (int i = 0; i + 1 < N - a; ++i) ce_kp<TOP>(k[i], p[i], k[i + 1], p[i + 1]);
+  }
+}
+
 template <bool TOP, int NG>
 __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_f, float *hbuf_f,
                                           uint32_t *posb, const uint16_t *cl, const int *clr,
@@ -367,19 +409,58 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
   if (steps == 0) return;
   const int worst = TOP ? kKeyMin : kKeyMax;
   if constexpr (NG > 0) {
+    // Heads of every group of four are kept SORTED in the strip (best first), payload = LDS position
+    // << 2 | group; so are the cached group winners.  A step then pops m[0], replaces the top of its
+    // group by the column's next key and re-inserts twice by a three-level bubble (max/min for the
+    // keys, one compare + two selects for the payloads): no slot bookkeeping, no runner-up scan.
     // clr: the row's local column ids, already in registers (one batch of independent loads)
-    int pos[4 * NG], hv[4 * NG];
+    int4 *hb4 = reinterpret_cast<int4 *>(hbuf);
+    uint4 *pb4 = reinterpret_cast<uint4 *>(posb);
+    int m[NG];
+    uint32_t pay[NG];
 #pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) {
-      pos[j] = (j < pd.W) ? clr[j] * pd.S_pad + (TOP ? 1 : pd.S) : 0;
-      hv[j] = (j < pd.W) ? colbuf[pos[j]] : worst;
-    }
+    for (int g = 0; g < NG; ++g) {
+      int hk[4];
+      uint32_t hp[4];
 #pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) {
-      const int idx = ((j >> 2) * RP + r) * 4 + (j & 3);
-      hbuf[idx] = hv[j];
-      posb[idx] = (uint32_t(pos[j]) << 8) | uint32_t(j);
+      for (int i = 0; i < 4; ++i) {
+        const int j = 4 * g + i;
+        const int pos = (j < pd.W) ? clr[j] * pd.S_pad + (TOP ? 1 : pd.S) : 0;
+        hk[i] = (j < pd.W) ? colbuf[pos] : worst;
+        hp[i] = (uint32_t(pos) << 2) | uint32_t(g);
+      }
+      sort4_best_first<TOP>(hk, hp);
+      hb4[g * RP + r] = make_int4(hk[0], hk[1], hk[2], hk[3]);
+      pb4[g * RP + r] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+      m[g] = hk[0];
+      pay[g] = hp[0];
     }
+    sort_best_first<TOP, NG>(m, pay);
+    int k = 0;
+    int next_rank = nt > 0 ? __builtin_amdgcn_readfirstlane(tgt[0].x) : -1;
+    int prev = worst;
+    for (int step = 0; step < steps; ++step) {
+      if (step == next_rank) {  // wave-uniform
+        emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, m[0], prev, rf, store, orow);
+        next_rank = __builtin_amdgcn_readfirstlane(next_rank);
+      }
+      prev = m[0];
+      const uint32_t g = pay[0] & 3u;
+      const int p = int(pay[0] >> 2) + (TOP ? 1 : -1);
+      const int gidx = int(g) * RP + r;
+      const int nk = colbuf[p];  // the column's sentinel once it is exhausted
+      const int4 h = hb4[gidx];
+      const uint4 q = pb4[gidx];
+      int hk[4] = {nk, h.y, h.z, h.w};
+      uint32_t hp[4] = {(uint32_t(p) << 2) | g, q.y, q.z, q.w};
+      insert_front<TOP, 4>(hk, hp);
+      hb4[gidx] = make_int4(hk[0], hk[1], hk[2], hk[3]);
+      pb4[gidx] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+      m[0] = hk[0];
+      pay[0] = hp[0];
+      insert_front<TOP, NG>(m, pay);
+    }
+    return;
   } else {
     for (int j = 0; j < pd.Wp; ++j) {
       const int idx = ((j >> 2) * RP + r) * 4 + (j & 3);
@@ -392,68 +473,11 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
       hbuf[idx] = h;
       posb[idx] = (uint32_t(pos) << 8) | uint32_t(j);
     }
-  }
-  int4 *hb4 = reinterpret_cast<int4 *>(hbuf);
-  uint4 *pb4 = reinterpret_cast<uint4 *>(posb);
-  int k = 0;
-  int next_rank = nt > 0 ? __builtin_amdgcn_readfirstlane(tgt[0].x) : -1;
-  int prev = worst;
-  if constexpr (NG > 0) {
-    int m[NG];
-    uint32_t pay[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) group_winner<TOP>(hb4[g * RP + r], pb4[g * RP + r], m[g], pay[g]);
-    int best = m[0];
-#pragma unroll
-    for (int g = 1; g < NG; ++g) best = kbest<TOP>(best, m[g]);
-    uint32_t bp = pay[0];
-#pragma unroll
-    for (int g = 1; g < NG; ++g) bp = (m[g] == best) ? pay[g] : bp;
-    for (int step = 0; step < steps; ++step) {
-      if (step == next_rank) {  // wave-uniform
-        emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, best, prev, rf, store, orow);
-        next_rank = __builtin_amdgcn_readfirstlane(next_rank);
-      }
-      prev = best;
-      const int bj = int(bp & 0xffu);
-      const int gw = bj >> 2, jw = bj & 3;
-      const int p = int(bp >> 8) + (TOP ? 1 : -1);
-      const int gidx = gw * RP + r;
-      // three independent reads: next key of the winning column, the winner's group
-      const int nk = colbuf[p];  // the column's sentinel once it is exhausted
-      int4 h = hb4[gidx];
-      uint4 q = pb4[gidx];
-      // --- in the shadow of those reads: the runner-up among the OTHER groups -----------------
-      int ru = worst;
-      uint32_t rup = 0;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int mo = (gw == g) ? worst : m[g];
-        const bool t = TOP ? (mo >= ru) : (mo <= ru);
-        ru = t ? mo : ru;
-        rup = t ? pay[g] : rup;
-      }
-      const uint32_t np = (uint32_t(p) << 8) | uint32_t(bj);
-      // --- needs the loaded data -----------------------------------------------------------------
-      h.x = (jw == 0) ? nk : h.x; q.x = (jw == 0) ? np : q.x;
-      h.y = (jw == 1) ? nk : h.y; q.y = (jw == 1) ? np : q.y;
-      h.z = (jw == 2) ? nk : h.z; q.z = (jw == 2) ? np : q.z;
-      h.w = (jw == 3) ? nk : h.w; q.w = (jw == 3) ? np : q.w;
-      hbuf[gidx * 4 + jw] = nk;
-      posb[gidx * 4 + jw] = np;
-      int mg;
-      uint32_t pg;
-      group_winner<TOP>(h, q, mg, pg);
-      const bool tw = TOP ? (mg >= ru) : (mg <= ru);
-      best = tw ? mg : ru;
-      bp = tw ? pg : rup;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        m[g] = (gw == g) ? mg : m[g];
-        pay[g] = (gw == g) ? pg : pay[g];
-      }
-    }
-  } else {
+    int4 *hb4 = reinterpret_cast<int4 *>(hbuf);
+    uint4 *pb4 = reinterpret_cast<uint4 *>(posb);
+    int k = 0;
+    int next_rank = nt > 0 ? __builtin_amdgcn_readfirstlane(tgt[0].x) : -1;
+    int prev = worst;
     const int ng = pd.Wp >> 2;
     for (int step = 0; step < steps; ++step) {
       int best = worst;
