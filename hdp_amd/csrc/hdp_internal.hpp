@@ -97,9 +97,10 @@ struct hdp_threshold_plan {
   bool pipe = false;
   int32_t lpc = 0;          // lanes per column of the register sort (1..16), 8 keys per lane
   int32_t n_merge = 0;      // waves that merge (ceil(rows_per_block / 64)); the rest produce
-  hdp::DevBuf tix;          // int32 [n_doy][8 * lpc] time index of sample e of a day-of-year column, -1 = none
-  hdp::DevBuf blk_col_off;  // int32 [n_blocks] offset into col_doy
-  hdp::DevBuf col_doy;      // int32 day-of-year row of each block-local column
+  hdp::DevBuf tix;          // int32 [block columns][8 * lpc] time index of sample e of a column, -1 = none
+  hdp::DevBuf blk_col_off;  // int32 [n_blocks] first row of each block in tix
+  hdp::DevBuf ninf;         // four floats, -inf
+  bool vec = false;         // lpc == 16 and the columns of every group of four are adjacent time steps
   mutable hdp::DevBuf clk;       // HDP_THR_DEBUG=8 phase clocks
 };
 

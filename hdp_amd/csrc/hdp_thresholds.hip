@@ -34,7 +34,8 @@ struct ThrDev {
   const uint16_t *cols_local;
   const QuantileParam *qp;
   const int2 *tgt_top, *tgt_bot;
-  const int32_t *tix, *blk_col_off, *col_doy;  // pipelined kernel: (column, sample) -> time index
+  const int32_t *tix, *blk_col_off;  // pipelined kernel: (block column, sample) -> time index
+  const float *ninf;                 // one -inf word (what a slot without a sample loads)
   int SL, n_merge;                             // pitch of tix (8 * lanes per column); merging waves
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
@@ -329,20 +330,45 @@ struct RowFlags {  // NaN / infinity census of the row's window (numba's special
 
 // Each requested quantile needs two ADJACENT order statistics, so it is finished the moment the
 // second one appears: `best` is the current merge output, `prev` the one before it.
+// Read-only plan tables indexed by a wave-uniform value: loaded through the constant address space so
+// the compiler emits scalar loads (s_load, scalar cache) instead of a vector load with a full
+// vmcnt(0) round trip in the middle of the merge.
+__device__ __forceinline__ long long ldk64(const void *p) {
+  typedef const __attribute__((address_space(4))) long long *kptr;
+  return *reinterpret_cast<kptr>(reinterpret_cast<uintptr_t>(p));
+}
+__device__ __forceinline__ int2 ldk(const int2 *p) {
+  const long long v = ldk64(p);
+  return make_int2(int(v), int(v >> 32));
+}
+__device__ __forceinline__ QuantileParam ldk(const QuantileParam *p) {
+  static_assert(sizeof(QuantileParam) == 24, "QuantileParam layout");
+  QuantileParam q;
+  q.mode = int(ldk64(p));
+  q.pad = 0;
+  q.w_lo = __longlong_as_double(ldk64(reinterpret_cast<const char *>(p) + 8));
+  q.w_hi = __longlong_as_double(ldk64(reinterpret_cast<const char *>(p) + 16));
+  return q;
+}
+
 template <bool TOP>
 __device__ __forceinline__ void emit_targets(const ThrDev &pd, const int2 *tgt, int nt, int &k, int &next_rank,
                                              int step, int best, int prev, const RowFlags &rf, bool store,
                                              double *orow) {
+  int kk = __builtin_amdgcn_readfirstlane(k);
+  int2 t = ldk(&tgt[kk]);
   do {
-    const int code = tgt[k].y;
-    const int p = code & 0xffff, kind = code >> 16;
+    const int p = t.y & 0xffff, kind = t.y >> 16;
     float lo = key_f32(best), hi = key_f32(best);
     if (kind == E_TOP_PAIR) hi = key_f32(prev);
     if (kind == E_BOT_PAIR) lo = key_f32(prev);
-    if (store) orow[p] = finish_quantile(pd.qp[p], lo, hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
-    ++k;
-  } while (k < nt && tgt[k].x == step);
-  next_rank = k < nt ? tgt[k].x : -1;
+    const QuantileParam qp = ldk(&pd.qp[p]);
+    if (store) orow[p] = finish_quantile(qp, lo, hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
+    ++kk;
+    t = kk < nt ? ldk(&tgt[kk]) : make_int2(-1, 0);
+  } while (t.x == step);
+  k = kk;
+  next_rank = t.x;
 }
 
 // ---- W-way merge, one lane per day-of-year row ------------------------------------------------
@@ -418,6 +444,8 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
     uint4 *pb4 = reinterpret_cast<uint4 *>(posb);
     int m[NG];
     uint32_t pay[NG];
+    unsigned long long tm0 = 0, tm1 = 0;
+    if (pd.debug & 512) tm0 = __builtin_readcyclecounter();
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       int hk[4];
@@ -437,8 +465,12 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
     }
     sort_best_first<TOP, NG>(m, pay);
     int k = 0;
-    int next_rank = nt > 0 ? __builtin_amdgcn_readfirstlane(tgt[0].x) : -1;
+    int next_rank = nt > 0 ? ldk(&tgt[0]).x : -1;
     int prev = worst;
+    if (pd.debug & 512) {
+      asm volatile("" ::"v"(m[0]));
+      tm1 = __builtin_readcyclecounter();
+    }
     for (int step = 0; step < steps; ++step) {
       if (step == next_rank) {  // wave-uniform
         emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, m[0], prev, rf, store, orow);
@@ -460,6 +492,12 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
       pay[0] = hp[0];
       insert_front<TOP, NG>(m, pay);
     }
+    if ((pd.debug & 512) && r == 0) {
+      asm volatile("" ::"v"(m[0]));
+      const unsigned long long tm2 = __builtin_readcyclecounter();
+      atomicAdd(&pd.clk[4], tm1 - tm0);
+      atomicAdd(&pd.clk[5], tm2 - tm1);
+    }
     return;
   } else {
     for (int j = 0; j < pd.Wp; ++j) {
@@ -476,7 +514,7 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
     int4 *hb4 = reinterpret_cast<int4 *>(hbuf);
     uint4 *pb4 = reinterpret_cast<uint4 *>(posb);
     int k = 0;
-    int next_rank = nt > 0 ? __builtin_amdgcn_readfirstlane(tgt[0].x) : -1;
+    int next_rank = nt > 0 ? ldk(&tgt[0]).x : -1;
     int prev = worst;
     const int ng = pd.Wp >> 2;
     for (int step = 0; step < steps; ++step) {
@@ -644,7 +682,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_kernel(ThrDev pd, c
 // "image written".  Results are identical to thresholds_kernel (same sort network, same merge).
 constexpr int kHold = 6;  // column groups a producer wave holds per block (8 VGPRs each)
 
-template <int LPC>
+template <int LPC, bool VEC>
 __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev pd, const float *__restrict__ x,
                                                                       int64_t n_cells,
                                                                       double *__restrict__ out) {
@@ -717,24 +755,67 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
         // ---- gather + sort block `s` in registers ------------------------------------------------
         const float *xc = x + cell_p * int64_t(pd.T);
         const int ncols = pd.blk_ncols[blk_p];
-        const int32_t *cd = pd.col_doy + pd.blk_col_off[blk_p];
+        // time indices of this block's columns: tix[(blk_col_off + column)][8 * LPC], -1 = no sample
+        const int32_t *tixb = pd.tix + size_t(pd.blk_col_off[blk_p]) * pd.SL;
         // lane coordinates re-materialised here: anything derived from them stays inside the producer
         // branch instead of being hoisted into registers that would be live across the merge
         int grp = lane / LPC, l = lane % LPC;
         asm volatile("" : "+v"(grp), "+v"(l));
+        // Two rounds of independent loads, no branches in between (groups past the end of the block
+        // re-read its last columns and are discarded): time indices, then samples.
+        if constexpr (VEC) {
+          // LPC == 16 and, for every sample e, the four columns of a group are adjacent in time (host-
+          // checked): lane `lane` loads 16 bytes = sample e = 64 k + lane of columns c..c+3, then a 4x4
+          // transpose between registers and DPP rows (two v_permlane32_swap + two v_permlane16_swap)
+          // leaves row r with column c + r: 4x fewer memory requests than one dword per (column, sample).
+          int tt[kHold][2];
 #pragma unroll
-        for (int j = 0; j < kHold; ++j) {
-          const int c0 = (pw + j * n_prod) * kCols;
-          if (c0 < ncols) {  // wave-uniform
-            const int lc = c0 + grp;
-            const bool active = lc < ncols;
-            const int doy = cd[active ? lc : c0];
-            const int4 *tp = reinterpret_cast<const int4 *>(pd.tix + size_t(doy) * pd.SL + l * 8);
+          for (int j = 0; j < kHold; ++j) {
+            const int cb = max(min((pw + j * n_prod) * kCols, ncols - kCols), 0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) tt[j][k] = tixb[size_t(cb) * pd.SL + k * 64 + lane];
+          }
+#pragma unroll
+          for (int j = 0; j < kHold; ++j) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int t = tt[j][k];
+              const float *src = (t >= 0) ? xc + t : pd.ninf;  // pd.ninf: four -inf words
+              float4 v;
+              __builtin_memcpy(&v, src, 16);  // global_load_dwordx4, any 4-byte alignment
+              uint32_t a0 = __float_as_uint(v.x), a1 = __float_as_uint(v.y);
+              uint32_t a2 = __float_as_uint(v.z), a3 = __float_as_uint(v.w);
+              auto s02 = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
+              auto s13 = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
+              auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+              auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+              hold[j][4 * k + 0] = __uint_as_float(s01[0]);  // sample 64 k + 16 i + (lane & 15) of column c + row
+              hold[j][4 * k + 1] = __uint_as_float(s01[1]);
+              hold[j][4 * k + 2] = __uint_as_float(s23[0]);
+              hold[j][4 * k + 3] = __uint_as_float(s23[1]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < kHold; ++j) {
+            const int lc = min((pw + j * n_prod) * kCols + grp, ncols - 1);
+            const int4 *tp = reinterpret_cast<const int4 *>(tixb + size_t(lc) * pd.SL + l * 8);
             const int4 ta = tp[0], tb = tp[1];
-            const int t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+            hold[j][0] = __int_as_float(ta.x); hold[j][1] = __int_as_float(ta.y);
+            hold[j][2] = __int_as_float(ta.z); hold[j][3] = __int_as_float(ta.w);
+            hold[j][4] = __int_as_float(tb.x); hold[j][5] = __int_as_float(tb.y);
+            hold[j][6] = __int_as_float(tb.z); hold[j][7] = __int_as_float(tb.w);
+          }
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-              hold[j][i] = (active && t[i] >= 0 && !(pd.debug & 4)) ? xc[t[i]] : -INFINITY;
+          for (int j = 0; j < kHold; ++j) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              // unconditional load through a selected base (slots without a sample read a -inf word):
+              // a select on the loaded value would make the compiler branch around every load and wait
+              const int t = __float_as_int(hold[j][i]);
+              const float *src = (t >= 0) ? xc : pd.ninf;
+              hold[j][i] = src[max(t, 0)];
+            }
           }
         }
         if (clocked) c1 = __builtin_readcyclecounter();
@@ -742,18 +823,21 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
         for (int j = 0; j < kHold; ++j) {
           const int c0 = (pw + j * n_prod) * kCols;
           if (c0 < ncols) {
-            const bool active = (c0 + grp) < ncols;
+            const int cb = VEC ? max(min(c0, ncols - kCols), 0) : c0;  // VEC: the last group overlaps its neighbour
+            const bool active = (cb + grp) < ncols;
             uint32_t cnt = 0;  // nan << 20 | +inf << 10 | -inf
             bool special = false;
+            // sample index held in register i before the sort
+            auto slot = [&](int i) { return VEC ? (i >> 2) * 64 + (i & 3) * 16 + l : l * 8 + i; };
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-              const bool real = active && (l * 8 + i) < pd.S;
+              const bool real = active && slot(i) < pd.S;
               special |= real && ((__float_as_uint(hold[j][i]) & 0x7f800000u) == 0x7f800000u);
             }
             if (__ballot(special) != 0) {
 #pragma unroll
               for (int i = 0; i < 8; ++i) {
-                const bool real = active && (l * 8 + i) < pd.S;
+                const bool real = active && slot(i) < pd.S;
                 float v = hold[j][i];
                 if (v != v) { cnt += 1u << 20; v = 0.0f; }
                 if (real && v == INFINITY) cnt += 1u << 10;
@@ -767,7 +851,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
             if constexpr (LPC >= 8) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppHalfMirror, 0xf, 0xf, false);
             if constexpr (LPC >= 16) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppMirror, 0xf, 0xf, false);
             if (active && l == 0)
-              flags_p[c0 + grp] = ((cnt >> 20) ? 0x80000000u : 0u) | (((cnt >> 10) & 0x3ffu) << 15) | (cnt & 0x3ffu);
+              flags_p[cb + grp] = ((cnt >> 20) ? 0x80000000u : 0u) | (((cnt >> 10) & 0x3ffu) << 15) | (cnt & 0x3ffu);
           }
         }
       }
@@ -799,8 +883,9 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
       asm volatile("" : "+v"(grp), "+v"(l));
 #pragma unroll
       for (int j = 0; j < kHold; ++j) {
-        const int lc = (pw + j * n_prod) * kCols + grp;
-        if (lc < ncols) {
+        const int c0 = (pw + j * n_prod) * kCols;
+        const int lc = (VEC ? max(min(c0, ncols - kCols), 0) : c0) + grp;
+        if (c0 < ncols && lc < ncols) {
           float *col = colbuf + lc * pd.S_pad + 1;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -823,7 +908,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
         atomicAdd(&pd.clk[1], c3 - c2);
         atomicAdd(&pd.clk[2], c5 - c3);
         atomicAdd(&pd.clk[3], 1ull);
-      } else {  // first producer wave: gather issue, sort (+ load wait), wait for the merge, write, barrier
+      } else if (!(pd.debug & 512)) {  // first producer wave: gather issue, sort (+ load wait), wait for the merge, write
         atomicAdd(&pd.clk[4], c1 - c0);
         atomicAdd(&pd.clk[5], c2 - c1);
         atomicAdd(&pd.clk[6], c3 - c2);
@@ -934,10 +1019,10 @@ static int launch_thr_epl(const ThrDev &pd, size_t lds, const float *x, int64_t 
   return HDP_OK;
 }
 
-template <int LPC>
+template <int LPC, bool VEC>
 static int launch_thr_pipe(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
                            hipStream_t stream) {
-  auto kern = thresholds_pipe_kernel<LPC>;
+  auto kern = thresholds_pipe_kernel<LPC, VEC>;
   HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // persistent workgroups: as many as the device keeps resident, each walking a strided set of cells
@@ -991,7 +1076,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.n = (int)plan->n;
   pd.tix = plan->tix.as<int32_t>();
   pd.blk_col_off = plan->blk_col_off.as<int32_t>();
-  pd.col_doy = plan->col_doy.as<int32_t>();
+  pd.ninf = plan->ninf.as<float>();
   pd.SL = 8 * plan->lpc;
   pd.n_merge = plan->n_merge;
   pd.debug = getenv("HDP_THR_DEBUG") ? atoi(getenv("HDP_THR_DEBUG")) : 0;
@@ -1006,11 +1091,16 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   const char *pipe_env = getenv("HDP_THR_PIPE");
   if (plan->pipe && !(pipe_env && atoi(pipe_env) == 0) && !(pd.debug & 8)) {
     switch (plan->lpc) {
-      case 1: return launch_thr_pipe<1>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      case 2: return launch_thr_pipe<2>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      case 4: return launch_thr_pipe<4>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      case 8: return launch_thr_pipe<8>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      default: return launch_thr_pipe<16>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 1: return launch_thr_pipe<1, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 2: return launch_thr_pipe<2, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 4: return launch_thr_pipe<4, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 8: return launch_thr_pipe<8, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      default: {
+        const char *vec_env = getenv("HDP_THR_VEC");
+        if (plan->vec && !(vec_env && atoi(vec_env) == 0))
+          return launch_thr_pipe<16, true>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+        return launch_thr_pipe<16, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      }
     }
   }
   switch (plan->epl) {
@@ -1264,16 +1354,35 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   up(pl->tgt_bot, tbot.data(), tbot.size() * sizeof(int2));
   if (lpc) {
     const int SL = 8 * lpc;
-    std::vector<int32_t> tix(size_t(n_doy) * SL, -1);
-    for (int64_t d = 0; d < n_doy; ++d)
+    std::vector<int32_t> tix(cdoy.size() * SL, -1);  // one row per (block, local column)
+    for (size_t c = 0; c < cdoy.size(); ++c)
       for (int64_t e = 0; e < S; ++e) {
-        int64_t t = time_index[d * S + e];
+        int64_t t = time_index[int64_t(cdoy[c]) * S + e];
         if (t < 0) t += T;
-        tix[size_t(d) * SL + e] = (int32_t)t;
+        tix[c * SL + e] = (int32_t)t;
       }
     up(pl->tix, tix.data(), tix.size() * 4);
     up(pl->blk_col_off, coff.data(), coff.size() * 4);
-    up(pl->col_doy, cdoy.data(), cdoy.size() * 4);
+    const float ninf4[4] = {-std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(),
+                            -std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity()};
+    up(pl->ninf, ninf4, sizeof ninf4);
+    // 16-byte gathers (lpc == 16): every group of four block columns, including the overlapping last
+    // one, must be four adjacent time steps for every sample
+    bool vec = (lpc == 16);
+    for (int b = 0; vec && b < pl->n_blocks; ++b) {
+      const int nc = ncols[b];
+      if (nc < 4) { vec = false; break; }
+      for (int c0 = 0; vec && c0 < nc; c0 += 4) {
+        const int cb = std::min(c0, nc - 4);
+        const int32_t *r0 = &tix[size_t(coff[b] + cb) * SL];
+        for (int j = 1; vec && j < 4; ++j) {
+          const int32_t *rj = &tix[size_t(coff[b] + cb + j) * SL];
+          for (int64_t e = 0; e < S; ++e)
+            if (rj[e] != r0[e] + j) { vec = false; break; }
+        }
+      }
+    }
+    pl->vec = vec;
   }
   if (e != hipSuccess) {
     delete pl;
