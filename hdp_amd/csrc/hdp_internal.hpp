@@ -100,7 +100,8 @@ struct hdp_threshold_plan {
   hdp::DevBuf tix;          // int32 [block columns][8 * lpc] time index of sample e of a column, -1 = none
   hdp::DevBuf blk_col_off;  // int32 [n_blocks] first row of each block in tix
   hdp::DevBuf ninf;         // four floats, -inf
-  bool vec = false;         // lpc == 16 and the columns of every group of four are adjacent time steps
+  bool vec = false;         // lpc == 16 and the block columns split into runs (>= 4) of adjacent time steps
+  hdp::DevBuf blk_grp_off, grp_col;  // vec: int32 [n_blocks + 1] offsets, first column of every group of four
   mutable hdp::DevBuf clk;       // HDP_THR_DEBUG=8 phase clocks
 };
 

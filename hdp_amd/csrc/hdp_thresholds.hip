@@ -35,7 +35,8 @@ struct ThrDev {
   const QuantileParam *qp;
   const int2 *tgt_top, *tgt_bot;
   const int32_t *tix, *blk_col_off;  // pipelined kernel: (block column, sample) -> time index
-  const float *ninf;                 // one -inf word (what a slot without a sample loads)
+  const float *ninf;                 // four -inf words (what a slot without a sample loads)
+  const int32_t *blk_grp_off, *grp_col;  // 16-byte gathers: first column of every group of four, per block
   int SL, n_merge;                             // pitch of tix (8 * lanes per column); merging waves
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
@@ -56,8 +57,11 @@ __device__ __forceinline__ int f32_key(float f) {
   return b ^ ((b >> 31) & 0x7fffffff);
 }
 __device__ __forceinline__ float key_f32(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
-constexpr int kKeyMax = 0x7fffffff;
-constexpr int kKeyMin = (int)0x80000000;
+// Sentinels: strictly beyond every real key (+inf is 0x7f800000, -inf is 0x807fffff; NaNs never reach
+// the keys).  Not INT_MAX / INT_MIN: packed with a payload and read as a double (pk_make below) these
+// two stay finite, normal numbers.
+constexpr int kKeyMax = 0x7f900000;
+constexpr int kKeyMin = (int)0x80400000;
 
 // ---- column sort: 64*EPL elements held as v[r] = element (r*64 + lane), descending ----
 // One compare-exchange stage: partner = e ^ mask, the element whose `top` bit is clear
@@ -372,58 +376,67 @@ __device__ __forceinline__ void emit_targets(const ThrDev &pd, const int2 *tgt, 
 }
 
 // ---- W-way merge, one lane per day-of-year row ------------------------------------------------
-// Heads (keys) and payloads live in a lane-private LDS strip [group of 4][row][4]; within a group the
-// heads are kept sorted best-first, and the group tops are cached, also sorted, in registers.  A step
-//   1. pops the best cached top m[0] (payload = LDS position << 2 | group),
+// A head is ONE 64-bit word: (order-preserving key, payload = LDS position << 2 | group), laid out so
+// that, read as a double, it is a positive normal number whose order is the (key, payload) order:
+//   hi = 0 | key ^ 0x80000000 (31 top bits),  lo = key bit 0 | payload (31 bits).
+// A compare-exchange of (key, payload) pairs is then v_max_f64 + v_min_f64 -- two instructions instead
+// of max, min, compare and two selects -- and moves the bits untouched (no arithmetic, no rounding).
+// Heads live in a lane-private LDS strip [group of 4][row][4], sorted best-first inside a group; the
+// group tops are cached, also sorted, in registers.  A step
+//   1. pops the best cached top m[0],
 //   2. issues, together, the read of that column's next key and of the winner's group,
-//   3. bubbles the new key into the group (three levels), writes the group back,
-//   4. bubbles the group's new top into the cached tops.
-// One LDS round trip and about 45 issue slots per step; only the first level of each bubble is on the
-// step-to-step critical path.  NG = ceil(W/4) is a template parameter (NG = 0: generic rescan loop
-// for very wide windows, payload = position << 8 | slot).
-template <bool TOP>
-__device__ __forceinline__ int kworst(int a, int b) { return TOP ? min(a, b) : max(a, b); }
-
-// compare-exchange of (key, payload) pairs: the better key ends up in a
-template <bool TOP>
-__device__ __forceinline__ void ce_kp(int &ka, uint32_t &pa, int &kb, uint32_t &pb) {
-  const bool swap = TOP ? (ka < kb) : (ka > kb);
-  const int hi = kbest<TOP>(ka, kb), lo = kworst<TOP>(ka, kb);
-  const uint32_t ph = swap ? pb : pa, pl = swap ? pa : pb;
-  ka = hi; kb = lo; pa = ph; pb = pl;
+//   3. bubbles the new head into the group (three compare-exchanges), writes the group back,
+//   4. bubbles the group's new top into the cached tops (three more).
+// One LDS round trip and about 25 issue slots per step.  NG = ceil(W/4) is a template parameter
+// (NG = 0: generic rescan loop on int keys for very wide windows, payload = position << 8 | slot).
+__device__ __forceinline__ double pk_max(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // not fmax(): no canonicalising pre-pass
+  return r;
 }
-
+__device__ __forceinline__ double pk_min(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double pk_make(int key, uint32_t pay) {
+  const uint32_t hi = (uint32_t(key) >> 1) ^ 0x40000000u;
+  const uint32_t lo = (uint32_t(key) << 31) | pay;
+  return __hiloint2double(int(hi), int(lo));
+}
+__device__ __forceinline__ int pk_key(double d) {
+  const uint32_t hi = uint32_t(__double2hiint(d)), lo = uint32_t(__double2loint(d));
+  return int(((hi << 1) | (lo >> 31)) ^ 0x80000000u);
+}
+// compare-exchange: the better head ends up in a
+template <bool TOP>
+__device__ __forceinline__ void ce_pk(double &a, double &b) {
+  const double hi = pk_max(a, b), lo = pk_min(a, b);
+  a = TOP ? hi : lo;
+  b = TOP ? lo : hi;
+}
 // k[1..N) is sorted best-first; k[0] is new: bubble it down to its place
 template <bool TOP, int N>
-__device__ __forceinline__ void insert_front(int (&k)[N], uint32_t (&p)[N]) {
+__device__ __forceinline__ void insert_front(double (&k)[N]) {
 #pragma unroll
-  for (int i = 0; i + 1 < N; ++i) ce_kp<TOP>(k[i], p[i], k[i + 1], p[i + 1]);
+  for (int i = 0; i + 1 < N; ++i) ce_pk<TOP>(k[i], k[i + 1]);
 }
-
-template <bool TOP>
-__device__ __forceinline__ void sort4_best_first(int (&k)[4], uint32_t (&p)[4]) {
-  ce_kp<TOP>(k[0], p[0], k[1], p[1]);
-  ce_kp<TOP>(k[2], p[2], k[3], p[3]);
-  ce_kp<TOP>(k[0], p[0], k[2], p[2]);
-  ce_kp<TOP>(k[1], p[1], k[3], p[3]);
-  ce_kp<TOP>(k[1], p[1], k[2], p[2]);
-}
-
 template <bool TOP, int N>
-__device__ __forceinline__ void sort_best_first(int (&k)[N], uint32_t (&p)[N]) {
+__device__ __forceinline__ void sort_best_first(double (&k)[N]) {
   if constexpr (N == 4) {
-    sort4_best_first<TOP>(k, p);
+    ce_pk<TOP>(k[0], k[1]); ce_pk<TOP>(k[2], k[3]); ce_pk<TOP>(k[0], k[2]); ce_pk<TOP>(k[1], k[3]);
+    ce_pk<TOP>(k[1], k[2]);
   } else {
 #pragma unroll
     for (int a = 0; a < N; ++a)
 #pragma unroll
-      for (int i = 0; i + 1 < N - a; ++i) ce_kp<TOP>(k[i], p[i], k[i + 1], p[i + 1]);
+      for (int i = 0; i + 1 < N - a; ++i) ce_pk<TOP>(k[i], k[i + 1]);
   }
 }
 
 template <bool TOP, int NG>
 __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_f, float *hbuf_f,
-                                          uint32_t *posb, const uint16_t *cl, const int *clr,
+                                          uint32_t *posb, const uint16_t *cl,
                                           int r /* row within block */, const RowFlags &rf, bool store,
                                           double *orow) {
   const int *colbuf = reinterpret_cast<const int *>(colbuf_f);
@@ -435,62 +448,70 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
   if (steps == 0) return;
   const int worst = TOP ? kKeyMin : kKeyMax;
   if constexpr (NG > 0) {
-    // Heads of every group of four are kept SORTED in the strip (best first), payload = LDS position
-    // << 2 | group; so are the cached group winners.  A step then pops m[0], replaces the top of its
-    // group by the column's next key and re-inserts twice by a three-level bubble (max/min for the
-    // keys, one compare + two selects for the payloads): no slot bookkeeping, no runner-up scan.
-    // clr: the row's local column ids, already in registers (one batch of independent loads)
-    int4 *hb4 = reinterpret_cast<int4 *>(hbuf);
-    uint4 *pb4 = reinterpret_cast<uint4 *>(posb);
-    int m[NG];
-    uint32_t pay[NG];
+    // strip halves: heads 0,1 of every (group, row) in the first, heads 2,3 in the second, so that a
+    // wave's 16-byte accesses are stride-16 in both (no bank conflicts)
+    double2 *sa = reinterpret_cast<double2 *>(hbuf);
+    double2 *sb = reinterpret_cast<double2 *>(posb);
+    double m[NG];
+    // the row's local column ids: one batch of independent loads (read again by the other direction
+    // rather than kept live across this merge)
+    int clr[4 * NG];
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) clr[j] = (j < pd.W) ? int(cl[j]) : 0;
     unsigned long long tm0 = 0, tm1 = 0;
     if (pd.debug & 512) tm0 = __builtin_readcyclecounter();
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      int hk[4];
-      uint32_t hp[4];
+      double hd[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = 4 * g + i;
         const int pos = (j < pd.W) ? clr[j] * pd.S_pad + (TOP ? 1 : pd.S) : 0;
-        hk[i] = (j < pd.W) ? colbuf[pos] : worst;
-        hp[i] = (uint32_t(pos) << 2) | uint32_t(g);
+        hd[i] = pk_make((j < pd.W) ? colbuf[pos] : worst, (uint32_t(pos) << 2) | uint32_t(g));
       }
-      sort4_best_first<TOP>(hk, hp);
-      hb4[g * RP + r] = make_int4(hk[0], hk[1], hk[2], hk[3]);
-      pb4[g * RP + r] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-      m[g] = hk[0];
-      pay[g] = hp[0];
+      sort_best_first<TOP, 4>(hd);
+      sa[g * RP + r] = make_double2(hd[0], hd[1]);
+      sb[g * RP + r] = make_double2(hd[2], hd[3]);
+      m[g] = hd[0];
     }
-    sort_best_first<TOP, NG>(m, pay);
+    sort_best_first<TOP, NG>(m);
     int k = 0;
     int next_rank = nt > 0 ? ldk(&tgt[0]).x : -1;
-    int prev = worst;
+    double prev = pk_make(worst, 0);
     if (pd.debug & 512) {
       asm volatile("" ::"v"(m[0]));
       tm1 = __builtin_readcyclecounter();
     }
-    for (int step = 0; step < steps; ++step) {
-      if (step == next_rank) {  // wave-uniform
-        emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, m[0], prev, rf, store, orow);
-        next_rank = __builtin_amdgcn_readfirstlane(next_rank);
+    // Steps run in emission-free stretches: inside a stretch only LDS operations are in flight, so the
+    // wait counters stay partial (a loop that can also reach the emission code, with its scalar loads,
+    // makes the compiler drain the previous step's strip writes before every step).
+    int step = 0;
+    while (true) {
+      const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
+      for (; step < stop; ++step) {
+        prev = m[0];
+        const uint32_t lo = uint32_t(__double2loint(m[0]));
+        const uint32_t g = lo & 3u;
+        const int gidx = __mul24(int(g), RP) + r;
+        // payload = position << 2 | group: position * 4 is the byte offset into the key image
+        const int nk = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(colbuf) +
+                                                       (lo & 0x7ffffffcu) + (TOP ? 4 : -4));
+        const double2 ha = sa[gidx];
+        const double2 hb = sb[gidx];
+        __builtin_amdgcn_sched_barrier(0);  // all three reads are in flight before anything waits on one
+        double hd[4] = {pk_make(nk, (lo & 0x7fffffffu) + (TOP ? 4u : -4u)), ha.y, hb.x, hb.y};
+        insert_front<TOP, 4>(hd);
+        if (!(pd.debug & 1024)) {
+          sa[gidx] = make_double2(hd[0], hd[1]);
+          sb[gidx] = make_double2(hd[2], hd[3]);
+        }
+        m[0] = hd[0];
+        insert_front<TOP, NG>(m);
       }
-      prev = m[0];
-      const uint32_t g = pay[0] & 3u;
-      const int p = int(pay[0] >> 2) + (TOP ? 1 : -1);
-      const int gidx = int(g) * RP + r;
-      const int nk = colbuf[p];  // the column's sentinel once it is exhausted
-      const int4 h = hb4[gidx];
-      const uint4 q = pb4[gidx];
-      int hk[4] = {nk, h.y, h.z, h.w};
-      uint32_t hp[4] = {(uint32_t(p) << 2) | g, q.y, q.z, q.w};
-      insert_front<TOP, 4>(hk, hp);
-      hb4[gidx] = make_int4(hk[0], hk[1], hk[2], hk[3]);
-      pb4[gidx] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-      m[0] = hk[0];
-      pay[0] = hp[0];
-      insert_front<TOP, NG>(m, pay);
+      if (step >= steps) break;
+      // step == next_rank: m[0] is order statistic `step`, prev the one before it
+      emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, pk_key(m[0]), pk_key(prev), rf, store && !(pd.debug & 2048), orow);
+      next_rank = __builtin_amdgcn_readfirstlane(next_rank);
     }
     if ((pd.debug & 512) && r == 0) {
       asm volatile("" ::"v"(m[0]));
@@ -543,18 +564,12 @@ template <int NG>
 __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf, float *hbuf, uint32_t *posb,
                                            const uint32_t *flags, const uint16_t *cl, int r, bool store,
                                            double *orow) {
-  // the row's column list: one batch of independent loads into registers (NG > 0)
-  int clr[NG > 0 ? 4 * NG : 1];
-  if constexpr (NG > 0) {
-#pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) clr[j] = (j < pd.W) ? int(cl[j]) : 0;
-  }
   RowFlags rf{0, 0};
   uint32_t nan_or = 0;
   if constexpr (NG > 0) {
 #pragma unroll
     for (int j = 0; j < 4 * NG; ++j) {
-      const uint32_t f = (j < pd.W) ? flags[clr[j]] : 0u;
+      const uint32_t f = (j < pd.W) ? flags[cl[j]] : 0u;
       nan_or |= f;
       rf.n_pos += (f >> 15) & 0x7fff;
       rf.n_neg += f & 0x7fff;
@@ -568,8 +583,8 @@ __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf
     }
   }
   if (nan_or >> 31) rf.n_pos = -1;
-  merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, clr, r, rf, store, orow);
-  merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, clr, r, rf, store, orow);
+  merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+  merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
 }
 
 template <int EPL>
@@ -702,6 +717,21 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
   float *hbuf = reinterpret_cast<float *>(smem + off);
   off += size_t(pd.Wp) * pd.RP * 4;
   uint32_t *posb = reinterpret_cast<uint32_t *>(smem + off);
+  off += size_t(pd.Wp) * pd.RP * 4;
+  uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][W] local columns of this block's windows
+
+  // One block of day-of-year rows per workgroup, for a strided set of cells: the block's tables are
+  // fixed for the workgroup's lifetime (window column lists staged in LDS once).
+  const int nb = pd.n_blocks;
+  const int blk = int(blockIdx.x) % nb;
+  const int64_t wg_per_blk = gridDim.x / nb;  // the host launches a multiple of n_blocks workgroups
+  const int64_t first_cell = int64_t(blockIdx.x) / nb;
+  const int64_t n_items = first_cell < n_cells ? (n_cells - first_cell + wg_per_blk - 1) / wg_per_blk : 0;
+  const int row0 = pd.blk_row0[blk];
+  const int nrows = pd.blk_nrows[blk];
+  const int ncols = pd.blk_ncols[blk];
+  const int32_t *tixb = pd.tix + size_t(pd.blk_col_off[blk]) * pd.SL;
+  for (int i = tid; i < nrows * pd.W; i += kThrThreads) cl_lds[i] = pd.cols_local[size_t(row0) * pd.W + i];
 
   // Roles.  The merge is a dependent chain that issues about one instruction per 8 cycles, so two
   // merging waves on one SIMD slow each other down (measured: +36 %) while a SIMD without any is
@@ -736,8 +766,19 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
   const int pw = rank - n_merge;           // producer index
   const int mrow = rank * 64 + lane;       // merging waves: row of the block this lane merges
 
-  const int64_t my_cells = (n_cells - int64_t(blockIdx.x) + gridDim.x - 1) / gridDim.x;
-  const int64_t n_items = my_cells * pd.n_blocks;  // (cell, block) pairs of this workgroup
+  // VEC (LPC == 16 and, for every sample e, the four columns of a group are adjacent in time; host-
+  // checked): lane `lane` loads 16 bytes = sample e = 64 k + lane of columns c..c+3, then a 4x4 transpose
+  // between registers and DPP rows (two v_permlane32_swap + two v_permlane16_swap) leaves row r with
+  // column c + r: 4x fewer memory requests than one dword per (column, sample).
+  int gc[VEC ? kHold : 1];  // first column of this producer wave's j-th group, -1: none (wave-uniform)
+  if constexpr (VEC) {
+    const int g0 = pd.blk_grp_off[blk], ng = pd.blk_grp_off[blk + 1] - g0;
+#pragma unroll
+    for (int j = 0; j < kHold; ++j) {
+      const int g = pw + j * n_prod;
+      gc[j] = __builtin_amdgcn_readfirstlane((producer && g < ng) ? pd.grp_col[g0 + g] : -1);
+    }
+  }
 
   for (int64_t s = 0; s <= n_items; ++s) {
     // sorted keys + census of this producer wave's column groups; defined and consumed inside one
@@ -748,53 +789,26 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;  // debug & 32: phase clocks
     const bool clocked = (pd.debug & 32) && lane == 0 && (rank == 0 || rank == n_merge);
     if (clocked) c0 = c1 = __builtin_readcyclecounter();
-    const int64_t cell_p = int64_t(blockIdx.x) + (s / pd.n_blocks) * gridDim.x;
-    const int blk_p = int(s % pd.n_blocks);
+    const int64_t cell_p = first_cell + s * wg_per_blk;
     if (producer) {
       if (s < n_items) {
         // ---- gather + sort block `s` in registers ------------------------------------------------
         const float *xc = x + cell_p * int64_t(pd.T);
-        const int ncols = pd.blk_ncols[blk_p];
-        // time indices of this block's columns: tix[(blk_col_off + column)][8 * LPC], -1 = no sample
-        const int32_t *tixb = pd.tix + size_t(pd.blk_col_off[blk_p]) * pd.SL;
+        // tixb: time indices of this block's columns, [column][8 * LPC], -1 = no sample
         // lane coordinates re-materialised here: anything derived from them stays inside the producer
         // branch instead of being hoisted into registers that would be live across the merge
         int grp = lane / LPC, l = lane % LPC;
         asm volatile("" : "+v"(grp), "+v"(l));
-        // Two rounds of independent loads, no branches in between (groups past the end of the block
-        // re-read its last columns and are discarded): time indices, then samples.
+        // Loads are branch-free (groups past the end of the block re-read its last columns and are
+        // discarded).  All time indices first; then the samples of group j + 1 are requested just
+        // before group j is sorted, so a producer wave keeps one group of loads in flight, not six: a
+        // full vector-memory queue would also stall the merging waves' quantile stores (in-order issue).
+        int tt[VEC ? kHold : 1][2];
         if constexpr (VEC) {
-          // LPC == 16 and, for every sample e, the four columns of a group are adjacent in time (host-
-          // checked): lane `lane` loads 16 bytes = sample e = 64 k + lane of columns c..c+3, then a 4x4
-          // transpose between registers and DPP rows (two v_permlane32_swap + two v_permlane16_swap)
-          // leaves row r with column c + r: 4x fewer memory requests than one dword per (column, sample).
-          int tt[kHold][2];
 #pragma unroll
-          for (int j = 0; j < kHold; ++j) {
-            const int cb = max(min((pw + j * n_prod) * kCols, ncols - kCols), 0);
+          for (int j = 0; j < kHold; ++j)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) tt[j][k] = tixb[size_t(cb) * pd.SL + k * 64 + lane];
-          }
-#pragma unroll
-          for (int j = 0; j < kHold; ++j) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const int t = tt[j][k];
-              const float *src = (t >= 0) ? xc + t : pd.ninf;  // pd.ninf: four -inf words
-              float4 v;
-              __builtin_memcpy(&v, src, 16);  // global_load_dwordx4, any 4-byte alignment
-              uint32_t a0 = __float_as_uint(v.x), a1 = __float_as_uint(v.y);
-              uint32_t a2 = __float_as_uint(v.z), a3 = __float_as_uint(v.w);
-              auto s02 = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
-              auto s13 = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
-              auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
-              auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
-              hold[j][4 * k + 0] = __uint_as_float(s01[0]);  // sample 64 k + 16 i + (lane & 15) of column c + row
-              hold[j][4 * k + 1] = __uint_as_float(s01[1]);
-              hold[j][4 * k + 2] = __uint_as_float(s23[0]);
-              hold[j][4 * k + 3] = __uint_as_float(s23[1]);
-            }
-          }
+            for (int k = 0; k < 2; ++k) tt[j][k] = tixb[size_t(max(gc[j], 0)) * pd.SL + k * 64 + lane];
         } else {
 #pragma unroll
           for (int j = 0; j < kHold; ++j) {
@@ -806,8 +820,18 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
             hold[j][4] = __int_as_float(tb.x); hold[j][5] = __int_as_float(tb.y);
             hold[j][6] = __int_as_float(tb.z); hold[j][7] = __int_as_float(tb.w);
           }
+        }
+        auto request = [&](int j) {  // samples of group j -> hold[j] (VEC: still register-major, see arrange)
+          if constexpr (VEC) {
 #pragma unroll
-          for (int j = 0; j < kHold; ++j) {
+            for (int k = 0; k < 2; ++k) {
+              const int t = tt[j][k];
+              const float *src = (t >= 0) ? xc + t : pd.ninf;  // pd.ninf: four -inf words
+              float4 v;
+              __builtin_memcpy(&v, src, 16);  // global_load_dwordx4, any 4-byte alignment
+              hold[j][4 * k + 0] = v.x; hold[j][4 * k + 1] = v.y; hold[j][4 * k + 2] = v.z; hold[j][4 * k + 3] = v.w;
+            }
+          } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               // unconditional load through a selected base (slots without a sample read a -inf word):
@@ -817,13 +841,26 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
               hold[j][i] = src[max(t, 0)];
             }
           }
-        }
-        if (clocked) c1 = __builtin_readcyclecounter();
+        };
+        auto finish = [&](int j) {  // (VEC: transpose,) census, sort
+          const int c0 = VEC ? gc[VEC ? j : 0] : (pw + j * n_prod) * kCols;
+          if (c0 >= 0 && c0 < ncols) {
+            if constexpr (VEC) {
 #pragma unroll
-        for (int j = 0; j < kHold; ++j) {
-          const int c0 = (pw + j * n_prod) * kCols;
-          if (c0 < ncols) {
-            const int cb = VEC ? max(min(c0, ncols - kCols), 0) : c0;  // VEC: the last group overlaps its neighbour
+              for (int k = 0; k < 2; ++k) {
+                const uint32_t a0 = __float_as_uint(hold[j][4 * k + 0]), a1 = __float_as_uint(hold[j][4 * k + 1]);
+                const uint32_t a2 = __float_as_uint(hold[j][4 * k + 2]), a3 = __float_as_uint(hold[j][4 * k + 3]);
+                auto s02 = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
+                auto s13 = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
+                auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+                auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+                hold[j][4 * k + 0] = __uint_as_float(s01[0]);  // sample 64 k + 16 i + (lane & 15) of column c + row
+                hold[j][4 * k + 1] = __uint_as_float(s01[1]);
+                hold[j][4 * k + 2] = __uint_as_float(s23[0]);
+                hold[j][4 * k + 3] = __uint_as_float(s23[1]);
+              }
+            }
+            const int cb = c0;
             const bool active = (cb + grp) < ncols;
             uint32_t cnt = 0;  // nan << 20 | +inf << 10 | -inf
             bool special = false;
@@ -853,18 +890,23 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
             if (active && l == 0)
               flags_p[cb + grp] = ((cnt >> 20) ? 0x80000000u : 0u) | (((cnt >> 10) & 0x3ffu) << 15) | (cnt & 0x3ffu);
           }
+        };
+        request(0);
+        if (clocked) c1 = __builtin_readcyclecounter();
+#pragma unroll
+        for (int j = 0; j < kHold; ++j) {
+          if (j + 1 < kHold) request(j + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          finish(j);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     } else if (s >= 1) {
       // ---- merge block `s - 1` out of the LDS image ----------------------------------------------
-      const int64_t sm = s - 1;
-      const int64_t cell = int64_t(blockIdx.x) + (sm / pd.n_blocks) * gridDim.x;
-      const int b = int(sm % pd.n_blocks);
-      const int row0 = pd.blk_row0[b];
-      const int nrows = pd.blk_nrows[b];
+      const int64_t cell = first_cell + (s - 1) * wg_per_blk;
       if (mrow < nrows && !(pd.debug & 1)) {
         const int row = row0 + mrow;
-        const uint16_t *cl = pd.cols_local + size_t(row) * pd.W;
+        const uint16_t *cl = cl_lds + mrow * pd.W;
         double *orow = out + (cell * pd.n_doy + row) * int64_t(pd.P);
         switch (pd.Wp >> 2) {
           case 1: merge_both<1>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow); break;
@@ -878,14 +920,13 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
     __syncthreads();  // image free (merge s-1 done), keys of block s sorted
     if (clocked) c3 = __builtin_readcyclecounter();
     if (producer && s < n_items) {
-      const int ncols = pd.blk_ncols[blk_p];
       int grp = lane / LPC, l = lane % LPC;
       asm volatile("" : "+v"(grp), "+v"(l));
 #pragma unroll
       for (int j = 0; j < kHold; ++j) {
-        const int c0 = (pw + j * n_prod) * kCols;
-        const int lc = (VEC ? max(min(c0, ncols - kCols), 0) : c0) + grp;
-        if (c0 < ncols && lc < ncols) {
+        const int c0 = VEC ? gc[VEC ? j : 0] : (pw + j * n_prod) * kCols;
+        const int lc = c0 + grp;
+        if (c0 >= 0 && lc < ncols) {
           float *col = colbuf + lc * pd.S_pad + 1;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -1036,8 +1077,11 @@ static int launch_thr_pipe(const ThrDev &pd, size_t lds, const float *x, int64_t
   HDP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern),
                                                            kThrThreads, lds));
   if (per_cu < 1) per_cu = 1;
-  int64_t grid = std::min<int64_t>(n_cells, int64_t(per_cu) * n_cu);
-  if (const char *env = getenv("HDP_THR_GRID")) grid = std::max<int64_t>(1, std::min<int64_t>(n_cells, atoll(env)));
+  // a multiple of n_blocks: workgroup w works on block w % n_blocks for cells w / n_blocks + k * (grid / n_blocks)
+  const int64_t nb = pd.n_blocks;
+  int64_t resident = int64_t(per_cu) * n_cu;
+  if (const char *env = getenv("HDP_THR_GRID")) resident = std::max<int64_t>(1, atoll(env));
+  int64_t grid = std::max<int64_t>(1, std::min<int64_t>(resident / nb, n_cells)) * nb;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThrThreads), lds, stream, pd, x, n_cells, out);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
@@ -1077,6 +1121,8 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.tix = plan->tix.as<int32_t>();
   pd.blk_col_off = plan->blk_col_off.as<int32_t>();
   pd.ninf = plan->ninf.as<float>();
+  pd.blk_grp_off = plan->blk_grp_off.as<int32_t>();
+  pd.grp_col = plan->grp_col.as<int32_t>();
   pd.SL = 8 * plan->lpc;
   pd.n_merge = plan->n_merge;
   pd.debug = getenv("HDP_THR_DEBUG") ? atoi(getenv("HDP_THR_DEBUG")) : 0;
@@ -1097,6 +1143,9 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
       case 8: return launch_thr_pipe<8, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       default: {
         const char *vec_env = getenv("HDP_THR_VEC");
+        if (pd.debug & 4096)
+          fprintf(stderr, "[hdp thresholds] pipe: vec plan=%d env=%s n_merge=%d rows=%d lds=%zu\n", (int)plan->vec,
+                  vec_env ? vec_env : "-", plan->n_merge, plan->rows_per_block, plan->lds_bytes);
         if (plan->vec && !(vec_env && atoi(vec_env) == 0))
           return launch_thr_pipe<16, true>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
         return launch_thr_pipe<16, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
@@ -1216,6 +1265,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     b += 2 * ((size_t(ncols) * 4 + 15) & ~size_t(15));  // census words (x2: pipelined kernel)
     b += size_t(pl->Wp) * RP * 4;       // heads
     b += size_t(pl->Wp) * RP * 4;       // position | slot payloads
+    b += (size_t(rows) * W * 2 + 15) & ~size_t(15);  // window column lists (pipelined kernel)
     return b;
   };
   auto cols_of_block = [&](int row0, int rows, std::vector<int> &set) {
@@ -1226,6 +1276,22 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
         const int c = cols[int64_t(r) * W + j];
         if (!seen[c]) { seen[c] = 1; set.push_back(c); }
       }
+    if (S > 64 && S <= 128 && n_doy >= 4) {
+      // 16-byte gathers work on runs of >= 4 consecutive day-of-year columns: a shorter run (the lone
+      // column 0 that the reflected upper edge keeps, threshold.py:43-48) is padded with its
+      // neighbours -- loaded and sorted like the rest, referenced by no window
+      for (int d = 0; d < n_doy;) {
+        if (!seen[d]) { ++d; continue; }
+        int e = d;
+        while (e + 1 < n_doy && seen[e + 1]) ++e;  // run [d, e]
+        for (int need = 4 - (e - d + 1); need > 0; --need) {
+          if (e + 1 < n_doy) { ++e; if (!seen[e]) { seen[e] = 2; set.push_back(e); } }
+          else if (d > 0) { --d; if (!seen[d]) { seen[d] = 2; set.push_back(d); } }
+        }
+        while (e + 1 < n_doy && seen[e + 1]) ++e;  // the padding may have touched the next run
+        d = e + 1;
+      }
+    }
     std::sort(set.begin(), set.end());
   };
   auto max_lds_for_rows = [&](int rows, int *ncols_max) -> size_t {
@@ -1366,21 +1432,44 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     const float ninf4[4] = {-std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(),
                             -std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity()};
     up(pl->ninf, ninf4, sizeof ninf4);
-    // 16-byte gathers (lpc == 16): every group of four block columns, including the overlapping last
-    // one, must be four adjacent time steps for every sample
+    // 16-byte gathers (lpc == 16): the block's columns are cut into runs of columns that are adjacent
+    // time steps for every sample; each run becomes groups of four (the last one of a run overlaps its
+    // neighbour).  A run shorter than four, or more groups than the producers can hold, disables it.
     bool vec = (lpc == 16);
+    std::vector<int32_t> goff, gcol;  // per block: offset into gcol; first column of each group
+    const int n_prod = hdp::kThrThreads / 64 - pl->n_merge;
     for (int b = 0; vec && b < pl->n_blocks; ++b) {
+      goff.push_back((int32_t)gcol.size());
       const int nc = ncols[b];
-      if (nc < 4) { vec = false; break; }
-      for (int c0 = 0; vec && c0 < nc; c0 += 4) {
-        const int cb = std::min(c0, nc - 4);
-        const int32_t *r0 = &tix[size_t(coff[b] + cb) * SL];
-        for (int j = 1; vec && j < 4; ++j) {
-          const int32_t *rj = &tix[size_t(coff[b] + cb + j) * SL];
+      int run0 = 0;
+      for (int c = 1; vec && c <= nc; ++c) {
+        bool adjacent = c < nc;
+        if (adjacent) {
+          const int32_t *ra = &tix[size_t(coff[b] + c - 1) * SL], *rb = &tix[size_t(coff[b] + c) * SL];
           for (int64_t e = 0; e < S; ++e)
-            if (rj[e] != r0[e] + j) { vec = false; break; }
+            if (rb[e] != ra[e] + 1) { adjacent = false; break; }
+        }
+        if (!adjacent) {  // run [run0, c)
+          const int len = c - run0;
+          if (len < 4) {
+            if (getenv("HDP_THR_DEBUG")) fprintf(stderr, "[hdp thresholds] vec off: block %d run [%d,%d)\n", b, run0, c);
+            vec = false;
+            break;
+          }
+          for (int o = 0; o < len; o += 4) gcol.push_back(run0 + std::min(o, len - 4));
+          run0 = c;
         }
       }
+      const int ng = int(gcol.size()) - goff.back();
+      if (vec && (ng + n_prod - 1) / n_prod > hdp::kHold) {
+        if (getenv("HDP_THR_DEBUG")) fprintf(stderr, "[hdp thresholds] vec off: block %d has %d groups for %d producers\n", b, ng, n_prod);
+        vec = false;
+      }
+    }
+    if (vec) {
+      goff.push_back((int32_t)gcol.size());
+      up(pl->blk_grp_off, goff.data(), goff.size() * 4);
+      up(pl->grp_col, gcol.data(), gcol.size() * 4);
     }
     pl->vec = vec;
   }
