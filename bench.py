@@ -276,7 +276,8 @@ def main():
         tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
         mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[0].data_ptr(), bc, out.data_ptr(), stream)
         torch.cuda.synchronize(dev)
-        th_gpu = thr[: ns * n_doy * P * 8].cpu().numpy().view(np.float64).reshape(ns, n_doy, P)
+        # device layout [cell][P][n_doy] -> the reference's (cell, doy, percentile)
+        th_gpu = thr[: ns * n_doy * P * 8].cpu().numpy().view(np.float64).reshape(ns, P, n_doy).transpose(0, 2, 1)
         out_gpu = out.view(4, P * D, bc, Yp)[:, :, :ns, :Y].cpu().numpy()
         met_gpu = np.transpose(out_gpu.reshape(4, P, D, ns, Y), (1, 2, 3, 0, 4)).astype(np.int64)
         parity = {"cells": ns, "thresholds_bit_exact": bool(np.array_equal(th_gpu, th_cpu)),

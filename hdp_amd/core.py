@@ -216,6 +216,7 @@ class ThresholdPlan:
         self.handle = h
 
     def run(self, x_ptr, n_cells, out_ptr, stream=None):
+        """Device pointers; out is [n_cells][P][n_doy] float64 (percentile-major, what MetricsPlan.run reads)."""
         _lib.check(self.lib.hdp_thresholds_f32_dev(self.handle, x_ptr, int(n_cells), out_ptr, stream))
 
     def __del__(self):
@@ -249,6 +250,7 @@ class MetricsPlan:
         _lib.check(self.lib.hdp_metrics_plan_reserve(self.handle, int(n_cells)))
 
     def run(self, x_ptr, thr_ptr, n_thr_cells, is_south_ptr, n_cells, out_ptr, stream=None):
+        """Device pointers; thr is [n_thr_cells][P][n_doy] float64 as written by ThresholdPlan.run."""
         _lib.check(self.lib.hdp_metrics_f32_dev(self.handle, x_ptr, thr_ptr, int(n_thr_cells), is_south_ptr,
                                                 int(n_cells), out_ptr, stream))
 

@@ -226,9 +226,10 @@ int hdp_thresholds_f32(const float *x, int64_t n_cells, int64_t T, int64_t strid
   std::unique_ptr<hdp_threshold_plan> guard(plan);
   if (n_cells == 0) return HDP_OK;
   const int64_t chunk = chunk_cells_for(n_cells, T * 4 + n_doy * P * 8);
-  DevBuf dx, dout;
+  DevBuf dx, dout, dref;
   HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
   HDP_HIP_TRY(dout.alloc(size_t(chunk) * n_doy * P * 8));
+  HDP_HIP_TRY(dref.alloc(size_t(chunk) * n_doy * P * 8));
   SeriesUploader up;
   for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
     const int64_t nc = std::min(chunk, n_cells - c0);
@@ -236,7 +237,10 @@ int hdp_thresholds_f32(const float *x, int64_t n_cells, int64_t T, int64_t strid
     if (rc != HDP_OK) return rc;
     rc = launch_thresholds(plan, dx.as<float>(), nc, dout.as<double>(), g_stream);
     if (rc != HDP_OK) return rc;
-    HDP_HIP_TRY(hipMemcpyAsync(out + c0 * n_doy * P, dout.p, size_t(nc) * n_doy * P * 8,
+    // device layout [cell][P][n_doy] -> the reference's (cell, doy, percentile)
+    rc = launch_swap_last2_f64(dout.as<double>(), nc, P, n_doy, dref.as<double>(), g_stream);
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipMemcpyAsync(out + c0 * n_doy * P, dref.p, size_t(nc) * n_doy * P * 8,
                                hipMemcpyDeviceToHost, g_stream));
     HDP_HIP_TRY(hipStreamSynchronize(g_stream));
   }
@@ -394,7 +398,14 @@ int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_c
   const int64_t Yp = plan->Ypitch;
   // thresholds stay resident for the whole call; series are processed in chunks
   DevBuf dthr, dx, dsouth, dout, dref;
-  HDP_HIP_TRY(dthr.upload(thr, size_t(n_thr_cells) * n_doy * P * 8));
+  {  // the reference's (cell, doy, percentile) -> device layout [cell][P][n_doy]
+    DevBuf dthr_ref;
+    HDP_HIP_TRY(dthr_ref.upload(thr, size_t(n_thr_cells) * n_doy * P * 8));
+    HDP_HIP_TRY(dthr.alloc(size_t(n_thr_cells) * n_doy * P * 8));
+    rc = launch_swap_last2_f64(dthr_ref.as<double>(), n_thr_cells, n_doy, P, dthr.as<double>(), g_stream);
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  }
   // chunks are multiples of n_thr_cells when members share thresholds, so (c % n_thr_cells) holds
   int64_t chunk = chunk_cells_for(n_cells, T * 4 + 4 * P * D * (Yp + Y) * 2);
   if (n_thr_cells < n_cells) {

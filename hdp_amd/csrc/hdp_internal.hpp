@@ -142,6 +142,8 @@ int launch_heat_index(const float *temp_dev, const float *rh_dev, int64_t n, flo
                       hipStream_t stream);
 int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
                      hipStream_t stream);
+int launch_swap_last2_f64(const double *src_dev, int64_t n, int64_t A, int64_t B, double *dst_dev,
+                          hipStream_t stream);
 int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,
                           int64_t Ypitch, int16_t *ref_layout, hipStream_t stream);
 

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_general(
       const int doy = d0 + lane;
       if (doy < md.n_doy)
         for (int q = 0; q < np; ++q)
-          thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(doy) * md.P + p_lo + q]);
+          thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(p_lo + q) * md.n_doy + doy]);
     }
   }
 
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
     const double *tc = thr + (cell % n_thr_cells) * int64_t(md.n_doy) * md.P;
     for (int doy = threadIdx.x; doy < md.n_doy; doy += 256)
       for (int q = 0; q < md.P; ++q)
-        thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(doy) * md.P + q]);
+        thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(q) * md.n_doy + doy]);
   }
   __syncthreads();
   const float *xc = x + cell * int64_t(md.T);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
       const int doy = d0 + lane;
       if (doy < md.n_doy)
         for (int q = 0; q < np; ++q)
-          thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(doy) * md.P + p_lo + q]);
+          thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(p_lo + q) * md.n_doy + doy]);
     }
   }
 
@@ -813,6 +813,31 @@ int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t
   dim3 grid((unsigned)((n + 63) / 64), (unsigned)((T + 63) / 64));
   HDP_REQUIRE(grid.y < 65536, HDP_EUNSUP, "time axis too long for the transpose launch");
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+static unsigned grid_for(int64_t total, int block);
+
+// per-cell transpose of an [A][B] float64 matrix: src [n][A][B] -> dst [n][B][A].  Converts between the
+// reference's threshold layout (doy, percentile) and the device layout (percentile, doy).
+__global__ void swap_last2_f64_kernel(const double *__restrict__ src, int64_t n, int A, int B,
+                                      double *__restrict__ dst) {
+  const int64_t total = n * A * B;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total;
+       i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t c = i / (int64_t(A) * B);
+    const int r = int(i % (int64_t(A) * B));
+    const int b = r / A, a = r % A;  // i indexes dst: [c][b][a]
+    dst[i] = src[(c * A + a) * int64_t(B) + b];
+  }
+}
+
+int launch_swap_last2_f64(const double *src_dev, int64_t n, int64_t A, int64_t B, double *dst_dev,
+                          hipStream_t stream) {
+  if (n * A * B == 0) return HDP_OK;
+  hipLaunchKernelGGL(swap_last2_f64_kernel, dim3(grid_for(n * A * B, 256)), dim3(256), 0, stream, src_dev, n,
+                     (int)A, (int)B, dst_dev);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
 }

@@ -367,7 +367,8 @@ __device__ __forceinline__ void emit_targets(const ThrDev &pd, const int2 *tgt, 
     if (kind == E_TOP_PAIR) hi = key_f32(prev);
     if (kind == E_BOT_PAIR) lo = key_f32(prev);
     const QuantileParam qp = ldk(&pd.qp[p]);
-    if (store) orow[p] = finish_quantile(qp, lo, hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
+    // percentile-major output: consecutive lanes (rows) write consecutive doubles
+    if (store) orow[size_t(p) * pd.n_doy] = finish_quantile(qp, lo, hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
     ++kk;
     t = kk < nt ? ldk(&tgt[kk]) : make_int2(-1, 0);
   } while (t.x == step);
@@ -485,33 +486,34 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
     // Steps run in emission-free stretches: inside a stretch only LDS operations are in flight, so the
     // wait counters stay partial (a loop that can also reach the emission code, with its scalar loads,
     // makes the compiler drain the previous step's strip writes before every step).
+    auto do_step = [&]() {
+      prev = m[0];
+      const uint32_t lo = uint32_t(__double2loint(m[0]));
+      const uint32_t g = lo & 3u;
+      const int gidx = __mul24(int(g), RP) + r;
+      // payload = position << 2 | group: position * 4 is the byte offset into the key image
+      const int nk = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(colbuf) +
+                                                     (lo & 0x7ffffffcu) + (TOP ? 4 : -4));
+      const double2 ha = sa[gidx];
+      const double2 hb = sb[gidx];
+      __builtin_amdgcn_sched_barrier(0);  // all three reads are in flight before anything waits on one
+      double hd[4] = {pk_make(nk, (lo & 0x7fffffffu) + (TOP ? 4u : -4u)), ha.y, hb.x, hb.y};
+      insert_front<TOP, 4>(hd);
+      sa[gidx] = make_double2(hd[0], hd[1]);
+      sb[gidx] = make_double2(hd[2], hd[3]);
+      m[0] = hd[0];
+      insert_front<TOP, NG>(m);
+    };
     int step = 0;
-    while (true) {
-      const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
-      for (; step < stop; ++step) {
-        prev = m[0];
-        const uint32_t lo = uint32_t(__double2loint(m[0]));
-        const uint32_t g = lo & 3u;
-        const int gidx = __mul24(int(g), RP) + r;
-        // payload = position << 2 | group: position * 4 is the byte offset into the key image
-        const int nk = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(colbuf) +
-                                                       (lo & 0x7ffffffcu) + (TOP ? 4 : -4));
-        const double2 ha = sa[gidx];
-        const double2 hb = sb[gidx];
-        __builtin_amdgcn_sched_barrier(0);  // all three reads are in flight before anything waits on one
-        double hd[4] = {pk_make(nk, (lo & 0x7fffffffu) + (TOP ? 4u : -4u)), ha.y, hb.x, hb.y};
-        insert_front<TOP, 4>(hd);
-        if (!(pd.debug & 1024)) {
-          sa[gidx] = make_double2(hd[0], hd[1]);
-          sb[gidx] = make_double2(hd[2], hd[3]);
-        }
-        m[0] = hd[0];
-        insert_front<TOP, NG>(m);
+    {
+      while (true) {
+        const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
+        for (; step < stop; ++step) do_step();
+        if (step >= steps) break;
+        // step == next_rank: m[0] is order statistic `step`, prev the one before it
+        emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, pk_key(m[0]), pk_key(prev), rf, store, orow);
+        next_rank = __builtin_amdgcn_readfirstlane(next_rank);
       }
-      if (step >= steps) break;
-      // step == next_rank: m[0] is order statistic `step`, prev the one before it
-      emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, pk_key(m[0]), pk_key(prev), rf, store && !(pd.debug & 2048), orow);
-      next_rank = __builtin_amdgcn_readfirstlane(next_rank);
     }
     if ((pd.debug & 512) && r == 0) {
       asm volatile("" ::"v"(m[0]));
@@ -666,7 +668,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_kernel(ThrDev pd, c
     if (tid < nrows) {
       const int row = row0 + tid;
       const uint16_t *cl = pd.cols_local + size_t(row) * pd.W;
-      double *orow = out + (cell * pd.n_doy + row) * int64_t(pd.P);
+      double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
       if (!(pd.debug & 1)) {
         switch (pd.Wp >> 2) {
           case 1: merge_both<1>(pd, colbuf, hbuf, posb, flags, cl, tid, true, orow); break;
@@ -697,7 +699,10 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_kernel(ThrDev pd, c
 // "image written".  Results are identical to thresholds_kernel (same sort network, same merge).
 constexpr int kHold = 6;  // column groups a producer wave holds per block (8 VGPRs each)
 
-template <int LPC, bool VEC>
+// NG (heads per row / 4; 0 = generic) is a kernel template parameter, not a run-time switch: a kernel that
+// carries every merge variant outgrows the instruction cache, and the misses showed up as 3-10x longer
+// start-up and write phases.
+template <int LPC, bool VEC, int NG>
 __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev pd, const float *__restrict__ x,
                                                                       int64_t n_cells,
                                                                       double *__restrict__ out) {
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
               const int t = tt[j][k];
-              const float *src = (t >= 0) ? xc + t : pd.ninf;  // pd.ninf: four -inf words
+              const float *src = (t >= 0 && !(pd.debug & 4)) ? xc + t : pd.ninf;  // pd.ninf: four -inf words
               float4 v;
               __builtin_memcpy(&v, src, 16);  // global_load_dwordx4, any 4-byte alignment
               hold[j][4 * k + 0] = v.x; hold[j][4 * k + 1] = v.y; hold[j][4 * k + 2] = v.z; hold[j][4 * k + 3] = v.w;
@@ -907,13 +912,8 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
       if (mrow < nrows && !(pd.debug & 1)) {
         const int row = row0 + mrow;
         const uint16_t *cl = cl_lds + mrow * pd.W;
-        double *orow = out + (cell * pd.n_doy + row) * int64_t(pd.P);
-        switch (pd.Wp >> 2) {
-          case 1: merge_both<1>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow); break;
-          case 2: merge_both<2>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow); break;
-          case 4: merge_both<4>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow); break;
-          default: merge_both<0>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow); break;
-        }
+        double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
+        merge_both<NG>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow);
       }
     }
     if (clocked) c2 = __builtin_readcyclecounter();
@@ -1060,10 +1060,10 @@ static int launch_thr_epl(const ThrDev &pd, size_t lds, const float *x, int64_t 
   return HDP_OK;
 }
 
-template <int LPC, bool VEC>
+template <int LPC, bool VEC, int NG>
 static int launch_thr_pipe(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
                            hipStream_t stream) {
-  auto kern = thresholds_pipe_kernel<LPC, VEC>;
+  auto kern = thresholds_pipe_kernel<LPC, VEC, NG>;
   HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // persistent workgroups: as many as the device keeps resident, each walking a strided set of cells
@@ -1085,6 +1085,18 @@ static int launch_thr_pipe(const ThrDev &pd, size_t lds, const float *x, int64_t
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThrThreads), lds, stream, pd, x, n_cells, out);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
+}
+
+// run-time (lanes per column, 16-byte gathers, head groups) -> kernel instantiation
+template <int LPC, bool VEC>
+static int launch_thr_pipe_ng(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
+                              hipStream_t stream) {
+  switch (pd.Wp >> 2) {
+    case 1: return launch_thr_pipe<LPC, VEC, 1>(pd, lds, x, n_cells, out, stream);
+    case 2: return launch_thr_pipe<LPC, VEC, 2>(pd, lds, x, n_cells, out, stream);
+    case 4: return launch_thr_pipe<LPC, VEC, 4>(pd, lds, x, n_cells, out, stream);
+    default: return launch_thr_pipe<LPC, VEC, 0>(pd, lds, x, n_cells, out, stream);
+  }
 }
 
 int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_t n_cells,
@@ -1137,18 +1149,18 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   const char *pipe_env = getenv("HDP_THR_PIPE");
   if (plan->pipe && !(pipe_env && atoi(pipe_env) == 0) && !(pd.debug & 8)) {
     switch (plan->lpc) {
-      case 1: return launch_thr_pipe<1, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      case 2: return launch_thr_pipe<2, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      case 4: return launch_thr_pipe<4, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      case 8: return launch_thr_pipe<8, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 1: return launch_thr_pipe_ng<1, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 2: return launch_thr_pipe_ng<2, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 4: return launch_thr_pipe_ng<4, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+      case 8: return launch_thr_pipe_ng<8, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       default: {
         const char *vec_env = getenv("HDP_THR_VEC");
         if (pd.debug & 4096)
           fprintf(stderr, "[hdp thresholds] pipe: vec plan=%d env=%s n_merge=%d rows=%d lds=%zu\n", (int)plan->vec,
                   vec_env ? vec_env : "-", plan->n_merge, plan->rows_per_block, plan->lds_bytes);
         if (plan->vec && !(vec_env && atoi(vec_env) == 0))
-          return launch_thr_pipe<16, true>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-        return launch_thr_pipe<16, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+          return launch_thr_pipe_ng<16, true>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
+        return launch_thr_pipe_ng<16, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       }
     }
   }

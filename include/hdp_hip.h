@@ -92,7 +92,10 @@ int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_doy, int64_t 
                               hdp_threshold_plan **plan_out);
 int hdp_threshold_plan_destroy(hdp_threshold_plan *plan);
 
-/* x_dev [n_cells][T] float32 time-contiguous -> out_dev [n_cells][n_doy][P] float64 */
+/* x_dev [n_cells][T] float32 time-contiguous -> out_dev [n_cells][P][n_doy] float64.
+ * PERCENTILE-MAJOR: the device layout, what hdp_metrics_f32_dev consumes (day-of-year rows are the
+ * kernels' lanes, so both sides of the hand-off are coalesced).  The host entry point below returns
+ * the reference's (cell, doy, percentile) order. */
 int hdp_thresholds_f32_dev(const hdp_threshold_plan *plan, const float *x_dev,
                            int64_t n_cells, double *out_dev, void *stream);
 
@@ -136,7 +139,8 @@ int hdp_metrics_plan_reserve(hdp_metrics_plan *plan, int64_t n_cells);
 int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan);
 
 /*
- * x_dev [n_cells][T] f32, thr_dev [n_thr_cells][n_doy][P] f64 where the thresholds of
+ * x_dev [n_cells][T] f32, thr_dev [n_thr_cells][P][n_doy] f64 (the layout hdp_thresholds_f32_dev
+ * writes; the host entry point takes the reference's [n_thr_cells][n_doy][P]) where the thresholds of
  * cell c are row (c % n_thr_cells) (ensemble members share their cell's thresholds
  * when series are ordered member-major), is_south_dev [n_cells] u8 ->
  * out_dev [4][P][D][n_cells][Ypitch] int16, metric order HWF, HWN, HWD, HWA
