@@ -1,0 +1,85 @@
+"""Every thresholds kernel variant against the C oracle and against each other (bit-exact).
+
+The library picks a kernel from the plan: the pipelined kernel (wave-specialised, register sort with
+8 * LPC keys per column, LPC in {1, 2, 4, 8, 16}; 16-byte gathers when the calendar is regular; merge
+templated on the number of head groups NG in {1, 2, 4}, generic rescan for wider windows) or the
+one-workgroup-per-cell kernel (HDP_THR_PIPE=0, also the path for more than 128 samples per column).
+The environment switches are read at launch, so one process can run them all on the same input.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from hdp_amd import calendar as cal  # noqa: E402
+from hdp_amd import core  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+from oracle import hdp_oracle as orc  # noqa: E402
+
+
+def same_f64(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+CASES = [
+    # (id, first date, last date, window radius, quantiles, cells, sprinkle special values)
+    ("S100-vec-ng4-top", "0001-01-01", "0100-12-31", 7, list(np.arange(0.9, 1.0, 0.01)), 5, False),
+    ("S100-vec-ng4-both", "0001-01-01", "0100-12-31", 7, [0.0, 0.03, 0.5, 0.97, 1.0], 3, True),
+    ("S70-ragged-novec", "0001-01-01", "0070-03-17", 7, [0.1, 0.9, 0.99], 4, True),
+    ("S40-lpc8-ng2", "0001-01-01", "0040-12-31", 3, [0.02, 0.5, 0.97], 6, False),
+    ("S20-lpc4-ng1", "0001-01-01", "0020-12-31", 1, [0.25, 0.95], 9, True),
+    ("S12-lpc2-generic", "0001-01-01", "0012-12-31", 10, [0.05, 0.9, 0.99], 7, False),
+    ("S5-lpc1-ng4", "0001-01-01", "0005-12-31", 7, [0.0, 0.9, 1.0], 11, True),
+    ("S3-lpc1-ragged", "0001-01-01", "0003-02-10", 7, [0.5, 0.9], 8, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
+    _, d0, d1, radius, q, n_cells, special = case
+    rng = np.random.default_rng(zlib.crc32(case[0].encode()))
+    dates = orc.noleap_date_range(d0, d1)
+    T = dates.size
+    t = np.arange(T)
+    x = (15 + 8 * np.sin(2 * np.pi * t / 365.0)[None, :] + rng.normal(0, 2.5, size=(n_cells, T))).astype(np.float32)
+    x[-1] = np.round(x[-1])                       # many exact ties
+    if special:
+        x[0, rng.integers(0, T, 3)] = np.inf
+        x[0, rng.integers(0, T, 2)] = -np.inf
+        x[1, rng.integers(0, T)] = np.nan
+        x[min(2, n_cells - 1), T - 1] = -np.inf   # the sample a -1 padded slot reads
+    ti, cols = cal.window_columns(dates, radius)
+    win = cal.expand_window_table(ti, cols)
+    with np.errstate(invalid="ignore"):
+        want = c_oracle.thresholds(x, win, q)
+
+    def run(**env):
+        for k in ("HDP_THR_PIPE", "HDP_THR_VEC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        return core.compute_percentiles(x, ti, cols, q)
+
+    got = run()
+    assert same_f64(got, want)
+    assert same_f64(run(HDP_THR_VEC="0"), want)       # pipelined kernel, one dword per (column, sample)
+    assert same_f64(run(HDP_THR_PIPE="0"), want)      # one workgroup per cell
+
+
+def test_pipelined_kernel_many_cells_vs_single_cell_launches():
+    """Persistent workgroups walk cells with a stride; every cell must come out as if it were alone
+    (no state leaks between the items of a workgroup, odd cell counts, more workgroups than cells)."""
+    rng = np.random.default_rng(77)
+    dates = orc.noleap_date_range("0001-01-01", "0030-12-31")
+    x = rng.normal(0, 3, size=(1543, dates.size)).astype(np.float32)
+    ti, cols = cal.window_columns(dates, 7)
+    q = [0.9, 0.95, 0.99]
+    got = core.compute_percentiles(x, ti, cols, q)
+    for c in (0, 1, 511, 512, 1023, 1542):
+        assert same_f64(got[c:c + 1], core.compute_percentiles(x[c:c + 1], ti, cols, q))
+    win = cal.expand_window_table(ti, cols)
+    sel = rng.choice(x.shape[0], 24, replace=False)
+    assert same_f64(got[sel], c_oracle.thresholds(x[sel], win, q))
