@@ -198,7 +198,9 @@ def main():
             traffic = float(tp[dom]["bytes_per_cell"]) * bc
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
+    dom_name = {"thresholds_kernel": "thresholds_pipe_kernel (sort producers + merge, one launch per band)",
+                "metrics_kernel": "exceed_kernel + metrics_kernel_uniform<true> (two launches per band, timed together)"}[dom]
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kern[dom]["frac_hbm"], "traffic": traffic,
                 "traffic_source": "rocprofv3 FETCH_SIZE/WRITE_SIZE per cell (profiles/) x cells per launch",
                 "both_kernels_frac": (bytes_thr + bytes_met) / (ms_thr + ms_met) / 1e6 / HBM_PEAK_GBS,
