@@ -768,6 +768,10 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
   }
   rank = __builtin_amdgcn_readfirstlane(rank);
   const bool producer = rank >= n_merge;  // wave-uniform
+  // The merging wave needs an issue slot every few cycles and shares its SIMD with three producer
+  // waves whose sorts are VALU-dense: without priority its chain runs 35 % slower (measured).
+  if (producer) __builtin_amdgcn_s_setprio(0);
+  else __builtin_amdgcn_s_setprio(3);
   const int pw = rank - n_merge;           // producer index
   const int mrow = rank * 64 + lane;       // merging waves: row of the block this lane merges
 
