@@ -932,10 +932,12 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
         const int lc = c0 + grp;
         if (c0 >= 0 && lc < ncols) {
           float *col = colbuf + lc * pd.S_pad + 1;
+          // branch-free: slots past the column's last sample all land on its trailing sentinel
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int e = l * 8 + i;
-            if (e < pd.S) col[e] = __int_as_float(f32_key(hold[j][i]));
+            const int key = (e < pd.S) ? f32_key(hold[j][i]) : kKeyMin;
+            col[min(e, pd.S)] = __int_as_float(key);
           }
           if (l == 0) {
             col[-1] = __int_as_float(kKeyMax);     // below every ascending walk

@@ -34,6 +34,11 @@ CASES = [
     ("S12-lpc2-generic", "0001-01-01", "0012-12-31", 10, [0.05, 0.9, 0.99], 7, False),
     ("S5-lpc1-ng4", "0001-01-01", "0005-12-31", 7, [0.0, 0.9, 1.0], 11, True),
     ("S3-lpc1-ragged", "0001-01-01", "0003-02-10", 7, [0.5, 0.9], 8, False),
+    # columns that fill their register slots exactly (S = 8 * LPC): no padding slot lands on the sentinel
+    ("S8-lpc1-full", "0001-01-01", "0008-12-31", 7, [0.1, 0.9], 5, True),
+    ("S16-lpc2-full", "0001-01-01", "0016-12-31", 2, [0.0, 0.5, 1.0], 5, False),
+    ("S64-lpc8-full", "0001-01-01", "0064-12-31", 7, [0.9, 0.99], 3, False),
+    ("S128-lpc16-full", "0001-01-01", "0128-12-31", 7, [0.05, 0.95], 2, True),
 ]
 
 
