@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
 }
 
 template <bool SPLIT>
-__global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_uniform(
+__global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
     MetDev md, const float *__restrict__ x, const double *__restrict__ thr, int64_t n_thr_cells,
     const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
