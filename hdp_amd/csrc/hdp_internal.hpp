@@ -113,7 +113,19 @@ struct hdp_metrics_plan {
   hdp::DevBuf doy_map;   // uint16 [T rounded up to 64]
   hdp::DevBuf defs;      // int32 [D][3]
   hdp::DevBuf seasons;   // int2 [2][Y]  (north, south)
-  mutable hdp::DevBuf bits_scratch;  // split path: exceedance words of one batch of series
+  mutable hdp::DevBuf bits_scratch;  // split path: exceedance words of two batches of series (double buffer)
+  // split path: the streaming exceedance kernel of batch b+1 runs on a second stream beside the
+  // VALU-bound state-machine kernel of batch b (created on first use, owned by the plan)
+  mutable hipStream_t aux_stream = nullptr;
+  mutable hipEvent_t ev_fork = nullptr, ev_exceed[2] = {nullptr, nullptr}, ev_state[2] = {nullptr, nullptr};
+  ~hdp_metrics_plan() {
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (int i = 0; i < 2; ++i) {
+      if (ev_exceed[i]) (void)hipEventDestroy(ev_exceed[i]);
+      if (ev_state[i]) (void)hipEventDestroy(ev_state[i]);
+    }
+    if (aux_stream) (void)hipStreamDestroy(aux_stream);
+  }
 };
 
 namespace hdp {

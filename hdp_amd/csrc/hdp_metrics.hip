@@ -873,6 +873,9 @@ __global__ void generate_kernel(float *__restrict__ x, int64_t n_cells, int64_t 
 int64_t metrics_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells, int64_t n_thr_cells) {
   const int64_t words_pad = ((((plan->T + 63) >> 6) + kCW - 1) / kCW) * kCW;
   const int64_t row_bytes = plan->P * words_pad * 8;
+  // the scratch is a double buffer of at most 2 x 4 GiB.  Batches stay as large as that allows: one wave
+  // of the state-machine kernel runs for about a millisecond, so a launch needs many waves per slot
+  // (8192 series per launch cost +20 % in tail effects)
   int64_t batch = std::max<int64_t>(1, (int64_t(4) << 30) / row_bytes);
   if (const char *env = getenv("HDP_METRICS_BATCH")) batch = std::max<int64_t>(1, atoll(env));
   if (n_thr_cells != n_cells && batch < n_cells)
@@ -883,7 +886,7 @@ int64_t metrics_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells, int64
 int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells) {
   if (!plan->uniform_seasons || n_cells <= 0) return HDP_OK;
   const int64_t words_pad = ((((plan->T + 63) >> 6) + kCW - 1) / kCW) * kCW;
-  const size_t need = size_t(metrics_batch_cells(plan, n_cells, n_cells)) * size_t(plan->P) * words_pad * 8;
+  const size_t need = 2 * size_t(metrics_batch_cells(plan, n_cells, n_cells)) * size_t(plan->P) * words_pad * 8;
   if (plan->bits_scratch.bytes >= need) return HDP_OK;
   hipError_t e = plan->bits_scratch.alloc(need);
   if (e != hipSuccess)
@@ -941,12 +944,28 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   // split path: exceedance words through an HBM scratch, in batches of series
   const size_t row_bytes = size_t(md.P) * md.words_pad * 8;
   const int64_t batch = metrics_batch_cells(plan, n_cells, n_thr_cells);
-  if (plan->bits_scratch.bytes < size_t(batch) * row_bytes) {
+  if (plan->bits_scratch.bytes < 2 * size_t(batch) * row_bytes) {
     HDP_HIP_TRY(hipStreamSynchronize(stream));  // the old scratch may still be in use
-    hipError_t e = plan->bits_scratch.alloc(size_t(batch) * row_bytes);
+    if (plan->aux_stream) HDP_HIP_TRY(hipStreamSynchronize(plan->aux_stream));
+    hipError_t e = plan->bits_scratch.alloc(2 * size_t(batch) * row_bytes);
     if (e != hipSuccess)
       return set_error(HDP_ENOMEM, "allocating %zu bytes of exceedance scratch failed: %s",
-                       size_t(batch) * row_bytes, hipGetErrorString(e));
+                       2 * size_t(batch) * row_bytes, hipGetErrorString(e));
+  }
+  const bool overlap = !(getenv("HDP_METRICS_OVERLAP") && atoi(getenv("HDP_METRICS_OVERLAP")) == 0);
+  if (overlap && !plan->aux_stream) {
+    HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream, hipStreamNonBlocking));
+    HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+      HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_exceed[i], hipEventDisableTiming));
+      HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_state[i], hipEventDisableTiming));
+    }
+  }
+  // fork: the exceedance kernels run on the plan's stream, behind everything already queued on `stream`
+  hipStream_t sx = overlap ? plan->aux_stream : stream;
+  if (overlap) {
+    HDP_HIP_TRY(hipEventRecord(plan->ev_fork, stream));
+    HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_fork, 0));
   }
   md.bits_g = plan->bits_scratch.as<unsigned long long>();
   const size_t lds_a = (size_t(md.P) * md.n_doy_pad * 4 + 15) & ~size_t(15);
@@ -956,8 +975,10 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   auto kern_b = metrics_kernel_uniform<true>;
   HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_b),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  for (int64_t c0 = 0; c0 < n_cells; c0 += batch) {
+  int64_t b = 0;
+  for (int64_t c0 = 0; c0 < n_cells; c0 += batch, ++b) {
     const int64_t nc = std::min(batch, n_cells - c0);
+    const int half = int(b & 1);
     // NOTE: series c of the batch is series c0 + c of the call: pointers are offset, the
     // (c % n_thr_cells) threshold mapping is kept by offsetting the threshold base when it is 1:1
     const bool one_to_one = (n_thr_cells == n_cells);
@@ -965,17 +986,24 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
                 "shared thresholds need batches aligned to the number of threshold cells");
     const double *thr_b = one_to_one ? thr_dev + c0 * int64_t(md.n_doy) * md.P : thr_dev;
     const int64_t ntc_b = one_to_one ? nc : n_thr_cells;
-    hipLaunchKernelGGL(exceed_kernel, dim3((unsigned)nc), dim3(256), lds_a, stream, md, x_dev + c0 * int64_t(md.T),
+    MetDev mb = md;
+    mb.bits_g = md.bits_g + size_t(half) * size_t(batch) * (row_bytes / 8);
+    mb.cell_off = c0;  // the state-machine kernel indexes the output with the FULL series count and this offset
+    // this half of the scratch is free once the state machine of batch b - 2 has read it
+    if (overlap && b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_state[half], 0));
+    hipLaunchKernelGGL(exceed_kernel, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_dev + c0 * int64_t(md.T),
                        thr_b, ntc_b, nc);
     HDP_HIP_TRY(hipGetLastError());
-    // the state-machine kernel indexes the output with the FULL series count and this batch's offset
-    MetDev mb = md;
-    mb.cell_off = c0;
+    if (overlap) {
+      HDP_HIP_TRY(hipEventRecord(plan->ev_exceed[half], sx));
+      HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->ev_exceed[half], 0));  // join (the last one closes the fork)
+    }
     const int64_t tasks = nc * md.n_groups;
     const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
     hipLaunchKernelGGL(kern_b, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, mb, x_dev, thr_b, ntc_b,
                        is_south_dev + c0, nc, out_dev);
     HDP_HIP_TRY(hipGetLastError());
+    if (overlap) HDP_HIP_TRY(hipEventRecord(plan->ev_state[half], stream));
   }
   return HDP_OK;
 }

@@ -130,8 +130,10 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy,
                             const int64_t *north, const int64_t *south, int64_t Y,
                             int64_t P, hdp_metrics_plan **plan_out);
 int hdp_metrics_plan_destroy(hdp_metrics_plan *plan);
-/* The default (split) metrics path keeps the exceedance words of one batch of series in an HBM
- * scratch owned by the plan (P * ceil(T/2048)*256 bytes per series, at most 4 GiB).  It is
+/* The default (split) metrics path keeps the exceedance words of two batches of series in an HBM
+ * scratch owned by the plan (P * ceil(T/2048)*256 bytes per series, at most 2 x 4 GiB; the streaming
+ * exceedance kernel of one batch runs on a stream of the plan's beside the state-machine kernel of the
+ * previous batch, forked from and joined back into the caller's stream).  It is
  * allocated on first use; call this once up front to keep hdp_metrics_f32_dev free of
  * allocations (stream capture, latency-sensitive callers).  Not thread-safe per plan. */
 int hdp_metrics_plan_reserve(hdp_metrics_plan *plan, int64_t n_cells);
