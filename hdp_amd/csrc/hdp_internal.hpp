@@ -114,6 +114,7 @@ struct hdp_metrics_plan {
   hdp::DevBuf defs;      // int32 [D][3]
   hdp::DevBuf seasons;   // int2 [2][Y]  (north, south)
   mutable hdp::DevBuf bits_scratch;  // split path: exceedance words of two batches of series (double buffer)
+  mutable hdp::DevBuf cm_scratch;    // split path: series-minor metrics of one batch, [4][P][D][Y][batch] int16
   // split path: the streaming exceedance kernel of batch b+1 runs on a second stream beside the
   // VALU-bound state-machine kernel of batch b (created on first use, owned by the plan)
   mutable hipStream_t aux_stream = nullptr;

@@ -610,6 +610,196 @@ __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
 #undef HDP_FINALIZE
 }
 
+// ---- split path, kernel 2': lane = series, one wave = 64 series x one percentile x up to 6 definitions ----
+// The six definitions of a percentile see the same runs, so a lane extracts each run of its series once
+// and steps the reference state machine (metric.py:39-58) of every definition with it; a run is skipped
+// only while no definition has a heatwave active and it is shorter than every min_duration (a no-op for
+// all of them).  Lock step is across 64 series of one percentile instead of across the (percentile,
+// definition) pairs of one series, the per-word overhead is shared by 64 series, and the results of a
+// season leave as 2-byte values that are contiguous across lanes: no per-lane packing registers.
+// Output (series-minor, batch-local): out_cm [4][P][D][Y][n_cells] int16; a transpose kernel turns it
+// into the device layout [4][P][D][series][Ypitch].
+struct CLane {  // per-definition state of a lane
+  int in_hw, subs, id;
+  int hwf, hwn, hwd, cur, last_id;
+};
+
+template <int DG>
+__global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md, const uint8_t *__restrict__ is_south,
+                                                                    int64_t n_cells, int16_t *__restrict__ out_cm) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_dpass = (md.D + DG - 1) / DG;
+  const int64_t n_grp = (n_cells + 63) >> 6;
+  const int64_t task = int64_t(blockIdx.x) * kMetWaves + wave;
+  if (task >= n_grp * md.P * n_dpass) return;  // no workgroup barriers in this kernel
+  const int d0 = int(task % n_dpass) * DG;
+  const int p = int((task / n_dpass) % md.P);
+  const int64_t cell = (task / (int64_t(n_dpass) * md.P)) * 64 + lane;
+  const bool valid = cell < n_cells;
+  const int my_hemi = valid ? int(is_south[cell]) : 2;
+  const unsigned long long *brow = md.bits_g + ((valid ? cell : 0) * md.P + p) * int64_t(md.words_pad);
+
+  // definition parameters of this pass (wave-uniform); slots past D never label and are not stored
+  int min_dur[DG], max_break[DG], max_subs[DG];
+  int mmin = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < DG; ++k) {
+    const bool real = d0 + k < md.D;
+    min_dur[k] = real ? md.defs[(d0 + k) * 3 + 0] : 0x3fffffff;
+    max_break[k] = real ? md.defs[(d0 + k) * 3 + 1] : 0;
+    max_subs[k] = real ? md.defs[(d0 + k) * 3 + 2] : 0;
+    mmin = min(mmin, max(min_dur[k], 1));
+  }
+  const int skip = min(mmin, 64);  // look-ahead of the run-skip shortcut is one 64-day word
+  const int Y = md.Y, dmax = md.dmax;
+  const int n_words = (md.T + 63) >> 6;
+  const int64_t plane = int64_t(Y) * n_cells;  // one (metric, percentile, definition) plane of out_cm
+
+  for (int h = 0; h < 2; ++h) {  // lanes of one hemisphere at a time: season bounds stay wave-uniform
+    const bool act = my_hemi == h;
+    if (__ballot(act) == 0) continue;
+    const int2 *seas = md.seasons + (h ? Y : 0);
+    int si = 0;
+    int sa = 0x7fffffff - 1024, sb = 0x7fffffff - 1024;
+    if (Y > 0) {
+      sa = __builtin_amdgcn_readfirstlane(seas[0].x);
+      sb = __builtin_amdgcn_readfirstlane(seas[0].y);
+    }
+    CLane st[DG];
+#pragma unroll
+    for (int k = 0; k < DG; ++k) {
+      st[k].in_hw = st[k].subs = st[k].id = 0;
+      st[k].hwf = st[k].hwn = st[k].hwd = st[k].cur = st[k].last_id = 0;
+    }
+    int open = 0, s_open = 0, e_prev = -(1 << 30);
+
+    auto credit_k = [&](CLane &c, int days, int run_id) {
+      const bool first = run_id != c.last_id;
+      c.hwf += days;
+      c.hwn += first ? 1 : 0;
+      c.cur = first ? days : c.cur + days;
+      c.last_id = run_id;
+      c.hwd = max(c.hwd, c.cur);
+    };
+    // one finished run [s, e): reference state machine + season credit, for every definition of the pass
+    auto close_run = [&](int s, int e) {
+      const int len = e - s;
+      const int days = min(e, sb) - max(s, sa);
+#pragma unroll
+      for (int k = 0; k < DG; ++k) {
+        CLane &c = st[k];
+        const bool ge = len >= min_dur[k];
+        const bool sub = c.in_hw && (c.subs < max_subs[k]);
+        const bool label = sub || ge;
+        c.subs = sub ? c.subs + 1 : (c.in_hw ? 0 : c.subs);
+        c.id += (ge && !sub) ? 1 : 0;
+        c.in_hw = label ? 1 : 0;
+        if (label && days > 0) credit_k(c, days, c.id);
+      }
+    };
+    // close season si (wave-uniform) for every lane and definition
+    auto finalize = [&](bool credit_open) {
+#pragma unroll
+      for (int k = 0; k < DG; ++k) {
+        CLane &c = st[k];
+        if (credit_open && open && s_open < sb) {
+          // a run still open dmax days past the season's end is labelled in every branch of the reference
+          const bool sub = c.in_hw && (c.subs < max_subs[k]);
+          credit_k(c, sb - max(s_open, sa), c.id + (sub ? 0 : 1));
+        }
+        if (act && d0 + k < md.D) {
+          const unsigned hwa = c.hwn ? (unsigned)c.hwf / (unsigned)c.hwn : 0u;  // == HWF // HWN
+          int16_t *o = out_cm + ((int64_t(p) * md.D + d0 + k) * Y + si) * n_cells + cell;
+          const int64_t mstride = int64_t(md.P) * md.D * plane;
+          o[0] = (int16_t)c.hwf;
+          o[mstride] = (int16_t)c.hwn;
+          o[2 * mstride] = (int16_t)c.hwd;
+          o[3 * mstride] = (int16_t)hwa;
+        }
+        c.hwf = c.hwn = c.hwd = c.cur = 0;
+        c.last_id = 0;
+      }
+      si += 1;
+      if (si < Y) {
+        sa = __builtin_amdgcn_readfirstlane(seas[si].x);
+        sb = __builtin_amdgcn_readfirstlane(seas[si].y);
+      } else {
+        sa = sb = 0x7fffffff - 1024;
+      }
+    };
+
+    unsigned long long cur = act ? brow[0] : 0ull;
+    for (int w = 0; w < n_words; ++w) {
+      const int t0 = w * 64;
+      while (si < Y && sb + dmax <= t0) finalize(true);  // wave-uniform
+      const unsigned long long word = cur;
+      const unsigned long long nxt = (act && w + 1 < n_words) ? brow[w + 1] : 0ull;  // beyond the record: not hot
+      cur = nxt;
+      // `longs`: bit i set iff days i..i+skip-1 are all hot (looking into the next word)
+      unsigned long long longs = word;
+      for (int k = 1; k < skip; ++k) longs &= (word >> k) | (nxt << (64 - k));
+      int any_hw = 0;
+#pragma unroll
+      for (int k = 0; k < DG; ++k) any_hw |= st[k].in_hw;
+      const bool work = open ? (word != ~0ull) : ((any_hw ? word : longs) != 0ull);
+      if (__ballot(work) == 0) continue;
+      int pos = 0;  // < 64 whenever it is used as a shift
+      while (true) {
+        if (!open) {
+          const unsigned long long r = (any_hw ? word : longs) >> pos;
+          if (r == 0) break;
+          pos += __builtin_ctzll(r);
+          s_open = t0 + pos;
+          open = 1;
+#pragma unroll
+          for (int k = 0; k < DG; ++k)
+            if (s_open - e_prev > max_break[k]) st[k].in_hw = 0;  // metric.py:48-49
+        }
+        const unsigned long long rz = (~word) >> pos;
+        if (rz == 0) break;  // the run continues into the next word
+        pos += __builtin_ctzll(rz);
+        const int e = t0 + pos;
+        open = 0;
+        close_run(s_open, e);
+        e_prev = e;
+        any_hw = 0;
+#pragma unroll
+        for (int k = 0; k < DG; ++k) any_hw |= st[k].in_hw;
+      }
+    }
+    if (open) {  // a run reaching the end of the record closes at T (metric.py:27: zero padding)
+      close_run(s_open, md.T);
+      open = 0;
+    }
+    while (si < Y) finalize(false);
+  }
+}
+
+// out_cm [planes][Y][nc] (series-minor) -> device layout [planes][n_total][Ypitch] at series offset cell_off.
+// One workgroup per (plane, 64 series): through an LDS tile so that both sides move whole lines.
+__global__ __launch_bounds__(256) void metrics_cells_to_rows_kernel(const int16_t *__restrict__ src, int Y, int64_t nc,
+                                                                   int16_t *__restrict__ dst, int64_t n_total,
+                                                                   int64_t cell_off, int Ypitch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int16_t *tile = reinterpret_cast<int16_t *>(smem);  // [64][Ypitch + 2]
+  const int TP = Ypitch + 2;
+  const int64_t c0 = int64_t(blockIdx.x) * 64;
+  const int64_t pl = blockIdx.y;
+  const int ncell = (int)min<int64_t>(64, nc - c0);
+  const int16_t *s = src + pl * int64_t(Y) * nc + c0;
+  for (int i = threadIdx.x; i < Y * 64; i += 256) {
+    const int y = i >> 6, c = i & 63;
+    if (c < ncell) tile[c * TP + y] = s[int64_t(y) * nc + c];
+  }
+  __syncthreads();
+  int16_t *d = dst + (pl * n_total + cell_off + c0) * Ypitch;
+  for (int i = threadIdx.x; i < ncell * Ypitch; i += 256) {
+    const int c = i / Ypitch, y = i % Ypitch;
+    d[i] = y < Y ? tile[c * TP + y] : (int16_t)0;
+  }
+}
+
 // device layout [4][P][D][n][Ypitch] -> reference block layout [P][D][n][4][Y]
 __global__ void metrics_repack_kernel(const int16_t *__restrict__ src, int64_t PD, int64_t n, int64_t Y,
                                       int64_t Ypitch, int16_t *__restrict__ dst) {
@@ -887,10 +1077,17 @@ int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells) {
   if (!plan->uniform_seasons || n_cells <= 0) return HDP_OK;
   const int64_t words_pad = ((((plan->T + 63) >> 6) + kCW - 1) / kCW) * kCW;
   const size_t need = 2 * size_t(metrics_batch_cells(plan, n_cells, n_cells)) * size_t(plan->P) * words_pad * 8;
-  if (plan->bits_scratch.bytes >= need) return HDP_OK;
-  hipError_t e = plan->bits_scratch.alloc(need);
-  if (e != hipSuccess)
-    return set_error(HDP_ENOMEM, "allocating %zu bytes of exceedance scratch failed: %s", need, hipGetErrorString(e));
+  if (plan->bits_scratch.bytes < need) {
+    hipError_t e = plan->bits_scratch.alloc(need);
+    if (e != hipSuccess)
+      return set_error(HDP_ENOMEM, "allocating %zu bytes of exceedance scratch failed: %s", need, hipGetErrorString(e));
+  }
+  const size_t need_cm = size_t(4) * plan->P * plan->D * plan->Y * size_t(metrics_batch_cells(plan, n_cells, n_cells)) * 2;
+  if (plan->cm_scratch.bytes < need_cm) {
+    hipError_t e = plan->cm_scratch.alloc(need_cm);
+    if (e != hipSuccess)
+      return set_error(HDP_ENOMEM, "allocating %zu bytes of metrics scratch failed: %s", need_cm, hipGetErrorString(e));
+  }
   return HDP_OK;
 }
 
@@ -952,6 +1149,18 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
       return set_error(HDP_ENOMEM, "allocating %zu bytes of exceedance scratch failed: %s",
                        2 * size_t(batch) * row_bytes, hipGetErrorString(e));
   }
+  // state machine with one series per lane (default) or one (percentile, definition) pair per lane
+  const bool by_cells = !(getenv("HDP_METRICS_CELLS") && atoi(getenv("HDP_METRICS_CELLS")) == 0) &&
+                        int64_t(4) * md.P * md.D < 65536 && md.Ypitch <= 2048;
+  if (by_cells) {
+    const size_t need = size_t(4) * md.P * md.D * md.Y * size_t(batch) * 2;
+    if (plan->cm_scratch.bytes < need) {
+      HDP_HIP_TRY(hipStreamSynchronize(stream));
+      hipError_t e = plan->cm_scratch.alloc(need);
+      if (e != hipSuccess)
+        return set_error(HDP_ENOMEM, "allocating %zu bytes of metrics scratch failed: %s", need, hipGetErrorString(e));
+    }
+  }
   const bool overlap = !(getenv("HDP_METRICS_OVERLAP") && atoi(getenv("HDP_METRICS_OVERLAP")) == 0);
   if (overlap && !plan->aux_stream) {
     HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream, hipStreamNonBlocking));
@@ -997,6 +1206,29 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     if (overlap) {
       HDP_HIP_TRY(hipEventRecord(plan->ev_exceed[half], sx));
       HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->ev_exceed[half], 0));  // join (the last one closes the fork)
+    }
+    if (by_cells) {
+      const int dg = md.D <= 6 ? md.D : 6;
+      const int64_t tasks = ((nc + 63) / 64) * md.P * ((md.D + dg - 1) / dg);
+      const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
+      HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
+      int16_t *cm = plan->cm_scratch.as<int16_t>();
+      const dim3 g((unsigned)blocks), t(kMetWaves * 64);
+      switch (dg) {
+        case 1: hipLaunchKernelGGL(metrics_kernel_cells<1>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
+        case 2: hipLaunchKernelGGL(metrics_kernel_cells<2>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
+        case 3: hipLaunchKernelGGL(metrics_kernel_cells<3>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
+        case 4: hipLaunchKernelGGL(metrics_kernel_cells<4>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
+        case 5: hipLaunchKernelGGL(metrics_kernel_cells<5>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
+        default: hipLaunchKernelGGL(metrics_kernel_cells<6>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
+      }
+      HDP_HIP_TRY(hipGetLastError());
+      if (overlap) HDP_HIP_TRY(hipEventRecord(plan->ev_state[half], stream));  // the bit words are consumed
+      const size_t tile = size_t(64) * (md.Ypitch + 2) * 2;
+      hipLaunchKernelGGL(metrics_cells_to_rows_kernel, dim3((unsigned)((nc + 63) / 64), (unsigned)(4 * md.P * md.D)),
+                         dim3(256), tile, stream, cm, md.Y, nc, out_dev, n_cells, c0, md.Ypitch);
+      HDP_HIP_TRY(hipGetLastError());
+      continue;
     }
     const int64_t tasks = nc * md.n_groups;
     const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
