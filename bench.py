@@ -280,8 +280,9 @@ def main():
         torch.cuda.synchronize(dev)
         # device layout [cell][P][n_doy] -> the reference's (cell, doy, percentile)
         th_gpu = thr[: ns * n_doy * P * 8].cpu().numpy().view(np.float64).reshape(ns, P, n_doy).transpose(0, 2, 1)
-        out_gpu = out.view(4, P * D, bc, Yp)[:, :, :ns, :Y].cpu().numpy()
-        met_gpu = np.transpose(out_gpu.reshape(4, P, D, ns, Y), (1, 2, 3, 0, 4)).astype(np.int64)
+        # device layout [4][P][D][Y][series] -> the reference's (percentile, definition, series, metric, year)
+        out_gpu = out.view(4, P * D, Y, bc)[:, :, :, :ns].cpu().numpy()
+        met_gpu = np.transpose(out_gpu.reshape(4, P, D, Y, ns), (1, 2, 4, 0, 3)).astype(np.int64)
         parity = {"cells": ns, "thresholds_bit_exact": bool(np.array_equal(th_gpu, th_cpu)),
                   "metrics_bit_exact": bool(np.array_equal(met_gpu, met_cpu))}
 

@@ -243,7 +243,8 @@ class MetricsPlan:
         self.year_pitch = int(self.lib.hdp_metrics_year_pitch(h))
 
     def out_shape(self, n_cells):
-        return (4, self.P, self.D, int(n_cells), self.year_pitch)
+        """Device layout of run()'s output: (metric, percentile, definition, year, series), int16."""
+        return (4, self.P, self.D, self.year_pitch, int(n_cells))
 
     def reserve(self, n_cells):
         """Allocate the exceedance scratch up front (keeps run() free of allocations)."""

@@ -361,7 +361,7 @@ int hdp_metrics_plan_destroy(hdp_metrics_plan *plan) {
   return HDP_OK;
 }
 
-int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan) { return plan ? plan->Ypitch : 0; }
+int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan) { return plan ? plan->Y : 0; }
 
 int hdp_metrics_plan_reserve(hdp_metrics_plan *plan, int64_t n_cells) {
   HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
@@ -395,7 +395,6 @@ int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_c
   if (rc != HDP_OK) return rc;
   std::unique_ptr<hdp_metrics_plan> guard(plan);
   if (n_cells == 0 || Y == 0) return HDP_OK;
-  const int64_t Yp = plan->Ypitch;
   // thresholds stay resident for the whole call; series are processed in chunks
   DevBuf dthr, dx, dsouth, dout, dref;
   {  // the reference's (cell, doy, percentile) -> device layout [cell][P][n_doy]
@@ -407,13 +406,13 @@ int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_c
     HDP_HIP_TRY(hipStreamSynchronize(g_stream));
   }
   // chunks are multiples of n_thr_cells when members share thresholds, so (c % n_thr_cells) holds
-  int64_t chunk = chunk_cells_for(n_cells, T * 4 + 4 * P * D * (Yp + Y) * 2);
+  int64_t chunk = chunk_cells_for(n_cells, T * 4 + 4 * P * D * (Y + Y) * 2);
   if (n_thr_cells < n_cells) {
     chunk = std::max<int64_t>(n_thr_cells, chunk / n_thr_cells * n_thr_cells);
   }
   HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
   HDP_HIP_TRY(dsouth.alloc(size_t(chunk)));
-  HDP_HIP_TRY(dout.alloc(size_t(4) * P * D * chunk * Yp * 2));
+  HDP_HIP_TRY(dout.alloc(size_t(4) * P * D * chunk * Y * 2));
   HDP_HIP_TRY(dref.alloc(size_t(4) * P * D * chunk * Y * 2));
   SeriesUploader up;
   std::vector<int16_t> host_ref(size_t(4) * P * D * chunk * Y);
@@ -428,7 +427,7 @@ int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_c
     rc = launch_metrics(plan, dx.as<float>(), thr_base, ntc, dsouth.as<uint8_t>(), nc, dout.as<int16_t>(),
                         g_stream);
     if (rc != HDP_OK) return rc;
-    rc = launch_metrics_repack(dout.as<int16_t>(), P, D, nc, Y, Yp, dref.as<int16_t>(), g_stream);
+    rc = launch_metrics_repack(dout.as<int16_t>(), P, D, nc, Y, dref.as<int16_t>(), g_stream);
     if (rc != HDP_OK) return rc;
     HDP_HIP_TRY(hipMemcpyAsync(host_ref.data(), dref.p, size_t(4) * P * D * nc * Y * 2,
                                hipMemcpyDeviceToHost, g_stream));

@@ -114,7 +114,7 @@ struct hdp_metrics_plan {
   hdp::DevBuf defs;      // int32 [D][3]
   hdp::DevBuf seasons;   // int2 [2][Y]  (north, south)
   mutable hdp::DevBuf bits_scratch;  // split path: exceedance words of two batches of series (double buffer)
-  mutable hdp::DevBuf cm_scratch;    // split path: series-minor metrics of one batch, [4][P][D][Y][batch] int16
+  mutable hdp::DevBuf rows_scratch;  // (percentile, definition)-per-lane kernels: [4][P][D][batch][Ypitch] int16
   // split path: the streaming exceedance kernel of batch b+1 runs on a second stream beside the
   // VALU-bound state-machine kernel of batch b (created on first use, owned by the plan)
   mutable hipStream_t aux_stream = nullptr;
@@ -158,7 +158,7 @@ int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t
 int launch_swap_last2_f64(const double *src_dev, int64_t n, int64_t A, int64_t B, double *dst_dev,
                           hipStream_t stream);
 int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,
-                          int64_t Ypitch, int16_t *ref_layout, hipStream_t stream);
+                          int16_t *ref_layout, hipStream_t stream);
 
 // numba rank arithmetic for one quantile over n samples; returns HDP_EQUANT for q
 // outside [0,1] (or NaN).  k_lo/k_hi are 0-based ASCENDING order-statistic indices.

@@ -617,8 +617,7 @@ __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
 // all of them).  Lock step is across 64 series of one percentile instead of across the (percentile,
 // definition) pairs of one series, the per-word overhead is shared by 64 series, and the results of a
 // season leave as 2-byte values that are contiguous across lanes: no per-lane packing registers.
-// Output (series-minor, batch-local): out_cm [4][P][D][Y][n_cells] int16; a transpose kernel turns it
-// into the device layout [4][P][D][series][Ypitch].
+// Output = the device layout, series-minor: out [4][P][D][Y][n_total] int16.
 struct CLane {  // per-definition state of a lane
   int in_hw, subs, id;
   int hwf, hwn, hwd, cur, last_id;
@@ -626,7 +625,7 @@ struct CLane {  // per-definition state of a lane
 
 template <int DG>
 __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md, const uint8_t *__restrict__ is_south,
-                                                                    int64_t n_cells, int16_t *__restrict__ out_cm) {
+                                                                    int64_t n_cells, int16_t *__restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_dpass = (md.D + DG - 1) / DG;
@@ -654,7 +653,8 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md
   const int skip = min(mmin, 64);  // look-ahead of the run-skip shortcut is one 64-day word
   const int Y = md.Y, dmax = md.dmax;
   const int n_words = (md.T + 63) >> 6;
-  const int64_t plane = int64_t(Y) * n_cells;  // one (metric, percentile, definition) plane of out_cm
+  const int64_t n_total = md.out_cells;          // series of the whole output; this launch starts at md.cell_off
+  const int64_t plane = int64_t(Y) * n_total;    // one (metric, percentile, definition) plane
 
   for (int h = 0; h < 2; ++h) {  // lanes of one hemisphere at a time: season bounds stay wave-uniform
     const bool act = my_hemi == h;
@@ -683,19 +683,34 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md
       c.hwd = max(c.hwd, c.cur);
     };
     // one finished run [s, e): reference state machine + season credit, for every definition of the pass
-    auto close_run = [&](int s, int e) {
+    // `may_credit` is wave-uniform: false for words that end before the current season starts (all lanes
+    // of a pass share the season table, and 55-60 % of a year is off-season), where the season sums
+    // cannot change and only the state machines are stepped
+    auto close_run = [&](int s, int e, bool may_credit) {
       const int len = e - s;
-      const int days = min(e, sb) - max(s, sa);
+      if (may_credit) {
+        const int days = min(e, sb) - max(s, sa);
 #pragma unroll
-      for (int k = 0; k < DG; ++k) {
-        CLane &c = st[k];
-        const bool ge = len >= min_dur[k];
-        const bool sub = c.in_hw && (c.subs < max_subs[k]);
-        const bool label = sub || ge;
-        c.subs = sub ? c.subs + 1 : (c.in_hw ? 0 : c.subs);
-        c.id += (ge && !sub) ? 1 : 0;
-        c.in_hw = label ? 1 : 0;
-        if (label && days > 0) credit_k(c, days, c.id);
+        for (int k = 0; k < DG; ++k) {
+          CLane &c = st[k];
+          const bool ge = len >= min_dur[k];
+          const bool sub = c.in_hw && (c.subs < max_subs[k]);
+          const bool label = sub || ge;
+          c.subs = sub ? c.subs + 1 : (c.in_hw ? 0 : c.subs);
+          c.id += (ge && !sub) ? 1 : 0;
+          c.in_hw = label ? 1 : 0;
+          if (label && days > 0) credit_k(c, days, c.id);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < DG; ++k) {
+          CLane &c = st[k];
+          const bool ge = len >= min_dur[k];
+          const bool sub = c.in_hw && (c.subs < max_subs[k]);
+          c.subs = sub ? c.subs + 1 : (c.in_hw ? 0 : c.subs);
+          c.id += (ge && !sub) ? 1 : 0;
+          c.in_hw = (sub || ge) ? 1 : 0;
+        }
       }
     };
     // close season si (wave-uniform) for every lane and definition
@@ -710,7 +725,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md
         }
         if (act && d0 + k < md.D) {
           const unsigned hwa = c.hwn ? (unsigned)c.hwf / (unsigned)c.hwn : 0u;  // == HWF // HWN
-          int16_t *o = out_cm + ((int64_t(p) * md.D + d0 + k) * Y + si) * n_cells + cell;
+          int16_t *o = out + ((int64_t(p) * md.D + d0 + k) * Y + si) * n_total + md.cell_off + cell;
           const int64_t mstride = int64_t(md.P) * md.D * plane;
           o[0] = (int16_t)c.hwf;
           o[mstride] = (int16_t)c.hwn;
@@ -744,6 +759,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md
       for (int k = 0; k < DG; ++k) any_hw |= st[k].in_hw;
       const bool work = open ? (word != ~0ull) : ((any_hw ? word : longs) != 0ull);
       if (__ballot(work) == 0) continue;
+      const bool may_credit = t0 + 64 > sa;  // wave-uniform; the current season is never one already closed
       int pos = 0;  // < 64 whenever it is used as a shift
       while (true) {
         if (!open) {
@@ -761,7 +777,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md
         pos += __builtin_ctzll(rz);
         const int e = t0 + pos;
         open = 0;
-        close_run(s_open, e);
+        close_run(s_open, e, may_credit);
         e_prev = e;
         any_hw = 0;
 #pragma unroll
@@ -769,40 +785,37 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md
       }
     }
     if (open) {  // a run reaching the end of the record closes at T (metric.py:27: zero padding)
-      close_run(s_open, md.T);
+      close_run(s_open, md.T, true);
       open = 0;
     }
     while (si < Y) finalize(false);
   }
 }
 
-// out_cm [planes][Y][nc] (series-minor) -> device layout [planes][n_total][Ypitch] at series offset cell_off.
-// One workgroup per (plane, 64 series): through an LDS tile so that both sides move whole lines.
-__global__ __launch_bounds__(256) void metrics_cells_to_rows_kernel(const int16_t *__restrict__ src, int Y, int64_t nc,
-                                                                   int16_t *__restrict__ dst, int64_t n_total,
-                                                                   int64_t cell_off, int Ypitch) {
+// Row layout of the (percentile, definition)-per-lane kernels, [planes][nc][Ypitch], -> device layout
+// [planes][Y][n_total] at series offset cell_off.  One workgroup per (plane, 64 series), through LDS.
+__global__ __launch_bounds__(256) void metrics_rows_to_cells_kernel(const int16_t *__restrict__ src, int Y, int64_t nc,
+                                                                   int Ypitch, int16_t *__restrict__ dst,
+                                                                   int64_t n_total, int64_t cell_off) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int16_t *tile = reinterpret_cast<int16_t *>(smem);  // [64][Ypitch + 2]
   const int TP = Ypitch + 2;
   const int64_t c0 = int64_t(blockIdx.x) * 64;
   const int64_t pl = blockIdx.y;
   const int ncell = (int)min<int64_t>(64, nc - c0);
-  const int16_t *s = src + pl * int64_t(Y) * nc + c0;
+  const int16_t *s = src + (pl * nc + c0) * Ypitch;
+  for (int i = threadIdx.x; i < ncell * Ypitch; i += 256) tile[(i / Ypitch) * TP + i % Ypitch] = s[i];
+  __syncthreads();
+  int16_t *d = dst + pl * int64_t(Y) * n_total + cell_off + c0;
   for (int i = threadIdx.x; i < Y * 64; i += 256) {
     const int y = i >> 6, c = i & 63;
-    if (c < ncell) tile[c * TP + y] = s[int64_t(y) * nc + c];
-  }
-  __syncthreads();
-  int16_t *d = dst + (pl * n_total + cell_off + c0) * Ypitch;
-  for (int i = threadIdx.x; i < ncell * Ypitch; i += 256) {
-    const int c = i / Ypitch, y = i % Ypitch;
-    d[i] = y < Y ? tile[c * TP + y] : (int16_t)0;
+    if (c < ncell) d[int64_t(y) * n_total + c] = tile[c * TP + y];
   }
 }
 
-// device layout [4][P][D][n][Ypitch] -> reference block layout [P][D][n][4][Y]
+// device layout [4][P][D][Y][n] -> reference block layout [P][D][n][4][Y]
 __global__ void metrics_repack_kernel(const int16_t *__restrict__ src, int64_t PD, int64_t n, int64_t Y,
-                                      int64_t Ypitch, int16_t *__restrict__ dst) {
+                                      int16_t *__restrict__ dst) {
   const int64_t total = PD * n * 4 * Y;
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total;
        i += int64_t(gridDim.x) * blockDim.x) {
@@ -810,7 +823,7 @@ __global__ void metrics_repack_kernel(const int16_t *__restrict__ src, int64_t P
     const int64_t m = (i / Y) % 4;
     const int64_t c = (i / (4 * Y)) % n;
     const int64_t pd = i / (4 * Y * n);
-    dst[i] = src[((m * PD + pd) * n + c) * Ypitch + y];
+    dst[i] = src[((m * PD + pd) * Y + y) * n + c];
   }
 }
 
@@ -1082,12 +1095,6 @@ int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells) {
     if (e != hipSuccess)
       return set_error(HDP_ENOMEM, "allocating %zu bytes of exceedance scratch failed: %s", need, hipGetErrorString(e));
   }
-  const size_t need_cm = size_t(4) * plan->P * plan->D * plan->Y * size_t(metrics_batch_cells(plan, n_cells, n_cells)) * 2;
-  if (plan->cm_scratch.bytes < need_cm) {
-    hipError_t e = plan->cm_scratch.alloc(need_cm);
-    if (e != hipSuccess)
-      return set_error(HDP_ENOMEM, "allocating %zu bytes of metrics scratch failed: %s", need_cm, hipGetErrorString(e));
-  }
   return HDP_OK;
 }
 
@@ -1115,8 +1122,16 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   md.out_cells = n_cells;
   md.cell_off = 0;
   md.words_pad = ((((md.T + 63) >> 6) + kCW - 1) / kCW) * kCW;
+  // Paths (same results; tests/test_gpu_parity.py runs them against each other):
+  //   split + by_cells  exceed_kernel -> metrics_kernel_cells (default)
+  //   split             exceed_kernel -> metrics_kernel_uniform<true>       HDP_METRICS_CELLS=0
+  //   fused             metrics_kernel_uniform<false>                       HDP_METRICS_FUSED=1
+  //   general           metrics_kernel_general: seasons closed per lane     close/unordered season tables
+  // The last three produce rows [4][P][D][series][Ypitch] in a scratch; a transpose brings them to the
+  // device layout [4][P][D][Y][series].
   const bool uniform = plan->uniform_seasons && !getenv("HDP_METRICS_GENERAL");
   const bool split = uniform && !getenv("HDP_METRICS_FUSED");
+  const bool by_cells = split && !(getenv("HDP_METRICS_CELLS") && atoi(getenv("HDP_METRICS_CELLS")) == 0);
   const size_t seas_bytes = uniform ? 0 : ((size_t(2) * md.Y * sizeof(int2) + 15) & ~size_t(15));
   const size_t thr_bytes = split ? 0 : ((size_t(md.np_max) * md.n_doy_pad * 4 + 15) & ~size_t(15));
   const size_t per_wave = thr_bytes + size_t(md.np_max) * (uniform ? kRow : kChunkWords) * 8;
@@ -1124,44 +1139,50 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   md.seas_bytes = (int)seas_bytes;
   md.thr_bytes = (int)thr_bytes;
   md.wave_bytes = (int)per_wave;
-  HDP_REQUIRE(lds <= kLdsPerCU - 1024, HDP_EUNSUP,
-              "metrics kernel needs %zu bytes of LDS (P=%d, n_doy=%d, Y=%d)", lds, md.P, md.n_doy, md.Y);
-  if (!split) {
-    const int64_t tasks = n_cells * md.n_groups;
-    const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
-    HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
-    auto kern = uniform ? metrics_kernel_uniform<false> : metrics_kernel_general;
-    HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, md, x_dev,
-                       thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev);
-    HDP_HIP_TRY(hipGetLastError());
-    return HDP_OK;
+  if (!by_cells)
+    HDP_REQUIRE(lds <= kLdsPerCU - 1024, HDP_EUNSUP,
+                "metrics kernel needs %zu bytes of LDS (P=%d, n_doy=%d, Y=%d)", lds, md.P, md.n_doy, md.Y);
+  HDP_REQUIRE(int64_t(4) * PD < 65536, HDP_EUNSUP, "too many (percentile, definition) pairs");
+
+  // every path works on batches of series: bounded scratch, and (split) overlap of the two kernels
+  const bool one_to_one = (n_thr_cells == n_cells);
+  const size_t row_bytes = size_t(md.P) * md.words_pad * 8;           // exceedance words of one series
+  const size_t rows_bytes = size_t(4) * PD * md.Ypitch * 2;           // row-layout metrics of one series
+  int64_t batch = split ? metrics_batch_cells(plan, n_cells, n_thr_cells) : n_cells;
+  if (!by_cells) {
+    int64_t cap = std::max<int64_t>(1, (int64_t(1) << 30) / (int64_t)rows_bytes);
+    if (!one_to_one && cap < n_cells) cap = std::max<int64_t>(n_thr_cells, cap / n_thr_cells * n_thr_cells);
+    batch = std::min(batch, cap);
   }
-  // split path: exceedance words through an HBM scratch, in batches of series
-  const size_t row_bytes = size_t(md.P) * md.words_pad * 8;
-  const int64_t batch = metrics_batch_cells(plan, n_cells, n_thr_cells);
-  if (plan->bits_scratch.bytes < 2 * size_t(batch) * row_bytes) {
+  auto grow = [&](hdp::DevBuf &buf, size_t need, const char *what) -> int {
+    if (buf.bytes >= need) return HDP_OK;
     HDP_HIP_TRY(hipStreamSynchronize(stream));  // the old scratch may still be in use
     if (plan->aux_stream) HDP_HIP_TRY(hipStreamSynchronize(plan->aux_stream));
-    hipError_t e = plan->bits_scratch.alloc(2 * size_t(batch) * row_bytes);
+    hipError_t e = buf.alloc(need);
     if (e != hipSuccess)
-      return set_error(HDP_ENOMEM, "allocating %zu bytes of exceedance scratch failed: %s",
-                       2 * size_t(batch) * row_bytes, hipGetErrorString(e));
+      return set_error(HDP_ENOMEM, "allocating %zu bytes of %s scratch failed: %s", need, what, hipGetErrorString(e));
+    return HDP_OK;
+  };
+  if (split) {
+    const int rc = grow(plan->bits_scratch, 2 * size_t(batch) * row_bytes, "exceedance");
+    if (rc != HDP_OK) return rc;
   }
-  // state machine with one series per lane (default) or one (percentile, definition) pair per lane
-  const bool by_cells = !(getenv("HDP_METRICS_CELLS") && atoi(getenv("HDP_METRICS_CELLS")) == 0) &&
-                        int64_t(4) * md.P * md.D < 65536 && md.Ypitch <= 2048;
-  if (by_cells) {
-    const size_t need = size_t(4) * md.P * md.D * md.Y * size_t(batch) * 2;
-    if (plan->cm_scratch.bytes < need) {
-      HDP_HIP_TRY(hipStreamSynchronize(stream));
-      hipError_t e = plan->cm_scratch.alloc(need);
-      if (e != hipSuccess)
-        return set_error(HDP_ENOMEM, "allocating %zu bytes of metrics scratch failed: %s", need, hipGetErrorString(e));
-    }
+  if (!by_cells) {
+    const int rc = grow(plan->rows_scratch, size_t(batch) * rows_bytes, "metrics row");
+    if (rc != HDP_OK) return rc;
   }
-  const bool overlap = !(getenv("HDP_METRICS_OVERLAP") && atoi(getenv("HDP_METRICS_OVERLAP")) == 0);
+  md.bits_g = plan->bits_scratch.as<unsigned long long>();
+  const size_t lds_a = (size_t(md.P) * md.n_doy_pad * 4 + 15) & ~size_t(15);
+  if (split) {
+    HDP_REQUIRE(lds_a <= kLdsPerCU - 1024, HDP_EUNSUP, "too many percentiles for the exceedance kernel");
+    HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(exceed_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+  }
+  auto kern_rows = split ? metrics_kernel_uniform<true> : (uniform ? metrics_kernel_uniform<false> : metrics_kernel_general);
+  if (!by_cells)
+    HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_rows),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool overlap = split && !(getenv("HDP_METRICS_OVERLAP") && atoi(getenv("HDP_METRICS_OVERLAP")) == 0);
   if (overlap && !plan->aux_stream) {
     HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream, hipStreamNonBlocking));
     HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
@@ -1176,66 +1197,64 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     HDP_HIP_TRY(hipEventRecord(plan->ev_fork, stream));
     HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_fork, 0));
   }
-  md.bits_g = plan->bits_scratch.as<unsigned long long>();
-  const size_t lds_a = (size_t(md.P) * md.n_doy_pad * 4 + 15) & ~size_t(15);
-  HDP_REQUIRE(lds_a <= kLdsPerCU - 1024, HDP_EUNSUP, "too many percentiles for the exceedance kernel");
-  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(exceed_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
-  auto kern_b = metrics_kernel_uniform<true>;
-  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_b),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int64_t b = 0;
   for (int64_t c0 = 0; c0 < n_cells; c0 += batch, ++b) {
     const int64_t nc = std::min(batch, n_cells - c0);
     const int half = int(b & 1);
-    // NOTE: series c of the batch is series c0 + c of the call: pointers are offset, the
-    // (c % n_thr_cells) threshold mapping is kept by offsetting the threshold base when it is 1:1
-    const bool one_to_one = (n_thr_cells == n_cells);
+    // series c of the batch is series c0 + c of the call: pointers are offset, the (c % n_thr_cells)
+    // threshold mapping is kept by offsetting the threshold base when it is 1:1
     HDP_REQUIRE(one_to_one || c0 % n_thr_cells == 0 || batch >= n_cells, HDP_EUNSUP,
                 "shared thresholds need batches aligned to the number of threshold cells");
     const double *thr_b = one_to_one ? thr_dev + c0 * int64_t(md.n_doy) * md.P : thr_dev;
     const int64_t ntc_b = one_to_one ? nc : n_thr_cells;
+    const float *x_b = x_dev + c0 * int64_t(md.T);
     MetDev mb = md;
     mb.bits_g = md.bits_g + size_t(half) * size_t(batch) * (row_bytes / 8);
-    mb.cell_off = c0;  // the state-machine kernel indexes the output with the FULL series count and this offset
-    // this half of the scratch is free once the state machine of batch b - 2 has read it
-    if (overlap && b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_state[half], 0));
-    hipLaunchKernelGGL(exceed_kernel, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_dev + c0 * int64_t(md.T),
-                       thr_b, ntc_b, nc);
-    HDP_HIP_TRY(hipGetLastError());
-    if (overlap) {
-      HDP_HIP_TRY(hipEventRecord(plan->ev_exceed[half], sx));
-      HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->ev_exceed[half], 0));  // join (the last one closes the fork)
+    if (split) {
+      // this half of the scratch is free once the state machine of batch b - 2 has read it
+      if (overlap && b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_state[half], 0));
+      hipLaunchKernelGGL(exceed_kernel, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
+      HDP_HIP_TRY(hipGetLastError());
+      if (overlap) {
+        HDP_HIP_TRY(hipEventRecord(plan->ev_exceed[half], sx));
+        HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->ev_exceed[half], 0));  // join (the last one closes the fork)
+      }
     }
     if (by_cells) {
+      mb.out_cells = n_cells;  // the device layout is indexed with the series of the whole call
+      mb.cell_off = c0;
       const int dg = md.D <= 6 ? md.D : 6;
       const int64_t tasks = ((nc + 63) / 64) * md.P * ((md.D + dg - 1) / dg);
       const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
       HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
-      int16_t *cm = plan->cm_scratch.as<int16_t>();
       const dim3 g((unsigned)blocks), t(kMetWaves * 64);
       switch (dg) {
-        case 1: hipLaunchKernelGGL(metrics_kernel_cells<1>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
-        case 2: hipLaunchKernelGGL(metrics_kernel_cells<2>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
-        case 3: hipLaunchKernelGGL(metrics_kernel_cells<3>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
-        case 4: hipLaunchKernelGGL(metrics_kernel_cells<4>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
-        case 5: hipLaunchKernelGGL(metrics_kernel_cells<5>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
-        default: hipLaunchKernelGGL(metrics_kernel_cells<6>, g, t, 0, stream, mb, is_south_dev + c0, nc, cm); break;
+        case 1: hipLaunchKernelGGL(metrics_kernel_cells<1>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
+        case 2: hipLaunchKernelGGL(metrics_kernel_cells<2>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
+        case 3: hipLaunchKernelGGL(metrics_kernel_cells<3>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
+        case 4: hipLaunchKernelGGL(metrics_kernel_cells<4>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
+        case 5: hipLaunchKernelGGL(metrics_kernel_cells<5>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
+        default: hipLaunchKernelGGL(metrics_kernel_cells<6>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
       }
       HDP_HIP_TRY(hipGetLastError());
-      if (overlap) HDP_HIP_TRY(hipEventRecord(plan->ev_state[half], stream));  // the bit words are consumed
-      const size_t tile = size_t(64) * (md.Ypitch + 2) * 2;
-      hipLaunchKernelGGL(metrics_cells_to_rows_kernel, dim3((unsigned)((nc + 63) / 64), (unsigned)(4 * md.P * md.D)),
-                         dim3(256), tile, stream, cm, md.Y, nc, out_dev, n_cells, c0, md.Ypitch);
-      HDP_HIP_TRY(hipGetLastError());
+      if (overlap) HDP_HIP_TRY(hipEventRecord(plan->ev_state[half], stream));
       continue;
     }
+    // (percentile, definition)-per-lane kernels: rows of this batch into the scratch, then transpose
+    mb.out_cells = nc;
+    mb.cell_off = 0;
     const int64_t tasks = nc * md.n_groups;
     const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
-    hipLaunchKernelGGL(kern_b, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, mb, x_dev, thr_b, ntc_b,
-                       is_south_dev + c0, nc, out_dev);
+    HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
+    int16_t *rows = plan->rows_scratch.as<int16_t>();
+    hipLaunchKernelGGL(kern_rows, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, mb, x_b, thr_b, ntc_b,
+                       is_south_dev + c0, nc, rows);
     HDP_HIP_TRY(hipGetLastError());
     if (overlap) HDP_HIP_TRY(hipEventRecord(plan->ev_state[half], stream));
+    const size_t tile = size_t(64) * (md.Ypitch + 2) * 2;
+    hipLaunchKernelGGL(metrics_rows_to_cells_kernel, dim3((unsigned)((nc + 63) / 64), (unsigned)(4 * PD)), dim3(256),
+                       tile, stream, rows, md.Y, nc, md.Ypitch, out_dev, n_cells, c0);
+    HDP_HIP_TRY(hipGetLastError());
   }
   return HDP_OK;
 }
@@ -1248,11 +1267,11 @@ static unsigned grid_for(int64_t total, int block) {
 }
 
 int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,
-                          int64_t Ypitch, int16_t *ref_layout, hipStream_t stream) {
+                          int16_t *ref_layout, hipStream_t stream) {
   const int64_t total = P * D * n_cells * 4 * Y;
   if (total == 0) return HDP_OK;
   hipLaunchKernelGGL(metrics_repack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, dev_layout,
-                     P * D, n_cells, Y, Ypitch, ref_layout);
+                     P * D, n_cells, Y, ref_layout);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
 }

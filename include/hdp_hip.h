@@ -137,7 +137,8 @@ int hdp_metrics_plan_destroy(hdp_metrics_plan *plan);
  * allocated on first use; call this once up front to keep hdp_metrics_f32_dev free of
  * allocations (stream capture, latency-sensitive callers).  Not thread-safe per plan. */
 int hdp_metrics_plan_reserve(hdp_metrics_plan *plan, int64_t n_cells);
-/* Row pitch (in int16 elements) of the device output: Y rounded up to 16 (32-byte rows). */
+/* Years (seasons) per series in the device output: the Y of the plan.  Kept for sizing the output
+ * buffer: 4 * P * D * hdp_metrics_year_pitch(plan) * n_cells int16 elements. */
 int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan);
 
 /*
@@ -145,7 +146,8 @@ int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan);
  * writes; the host entry point takes the reference's [n_thr_cells][n_doy][P]) where the thresholds of
  * cell c are row (c % n_thr_cells) (ensemble members share their cell's thresholds
  * when series are ordered member-major), is_south_dev [n_cells] u8 ->
- * out_dev [4][P][D][n_cells][Ypitch] int16, metric order HWF, HWN, HWD, HWA
+ * out_dev [4][P][D][Y][n_cells] int16 (series-minor: a lane of the state-machine kernel is a series, so a
+ * season's results leave as contiguous 2-byte values), metric order HWF, HWN, HWD, HWA
  * (metric.py:336-340).  Values are bounded by the season length (< 32768).
  */
 int hdp_metrics_f32_dev(const hdp_metrics_plan *plan, const float *x_dev,
