@@ -117,7 +117,7 @@ struct hdp_metrics_plan {
   mutable hdp::DevBuf rows_scratch;  // (percentile, definition)-per-lane kernels: [4][P][D][batch][Ypitch] int16
   // split path: the streaming exceedance kernel of batch b+1 runs on a second stream beside the
   // VALU-bound state-machine kernel of batch b (created on first use, owned by the plan)
-  mutable hipStream_t aux_stream = nullptr;
+  mutable hipStream_t aux_stream = nullptr, aux_stream2 = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_exceed[2] = {nullptr, nullptr}, ev_state[2] = {nullptr, nullptr};
   ~hdp_metrics_plan() {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -126,6 +126,7 @@ struct hdp_metrics_plan {
       if (ev_state[i]) (void)hipEventDestroy(ev_state[i]);
     }
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
+    if (aux_stream2) (void)hipStreamDestroy(aux_stream2);
   }
 };
 

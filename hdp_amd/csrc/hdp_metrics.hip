@@ -618,13 +618,16 @@ __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
 // definition) pairs of one series, the per-word overhead is shared by 64 series, and the results of a
 // season leave as 2-byte values that are contiguous across lanes: no per-lane packing registers.
 // Output = the device layout, series-minor: out [4][P][D][Y][n_total] int16.
+constexpr int kSlotPitch = 80;  // bytes per lane of the word slots in LDS
 struct CLane {  // per-definition state of a lane
   int in_hw, subs, id;
   int hwf, hwn, hwd, cur, last_id;
 };
 
+// At most 5 waves per SIMD (the kernel is VALU-bound and no faster with 7): the exceedance kernel of the
+// next batch runs beside it and needs wave slots of its own, or it becomes the slower stage of the pipeline.
 template <int DG>
-__global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md, const uint8_t *__restrict__ is_south,
+__global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 5))) void metrics_kernel_cells(MetDev md, const uint8_t *__restrict__ is_south,
                                                                     int64_t n_cells, int16_t *__restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -638,6 +641,11 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md
   const bool valid = cell < n_cells;
   const int my_hemi = valid ? int(is_south[cell]) : 2;
   const unsigned long long *brow = md.bits_g + ((valid ? cell : 0) * md.P + p) * int64_t(md.words_pad);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // lane-private 64-byte slot (pitch 80 bytes: lanes spread over the banks)
+  unsigned char *slot = smem + (size_t(wave) * 64 + lane) * kSlotPitch;
+  uint4 *slot4 = reinterpret_cast<uint4 *>(slot);
+  const unsigned long long *slot8 = reinterpret_cast<const unsigned long long *>(slot);
 
   // definition parameters of this pass (wave-uniform); slots past D never label and are not stored
   int min_dur[DG], max_break[DG], max_subs[DG];
@@ -744,13 +752,27 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_cells(MetDev md
       }
     };
 
-    unsigned long long cur = act ? brow[0] : 0ull;
+    // The lane's words come in blocks of eight (one 64-byte line per lane and block, four 16-byte loads that
+    // hit the same line): block b + 1 is in flight while block b, parked in a lane-private LDS slot, is walked
+    // word by word.  Word-at-a-time loads re-fetched every line up to eight times (6.7x the bytes).
+    const uint4 *bline = reinterpret_cast<const uint4 *>(brow);
+    uint4 pf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pf[q] = act ? bline[q] : make_uint4(0, 0, 0, 0);
     for (int w = 0; w < n_words; ++w) {
       const int t0 = w * 64;
+      if ((w & 7) == 0) {  // wave-uniform: park the fetched block, request the next one
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slot4[q] = pf[q];
+        const bool more = act && (w + 8 < md.words_pad);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pf[q] = more ? bline[(w >> 1) + 4 + q] : make_uint4(0, 0, 0, 0);
+      }
       while (si < Y && sb + dmax <= t0) finalize(true);  // wave-uniform
-      const unsigned long long word = cur;
-      const unsigned long long nxt = (act && w + 1 < n_words) ? brow[w + 1] : 0ull;  // beyond the record: not hot
-      cur = nxt;
+      const unsigned long long word = slot8[w & 7];
+      // the word after it: next in the slot, or the first word of the block in flight; beyond the record: not hot
+      const unsigned long long nxt =
+          (w & 7) != 7 ? slot8[(w & 7) + 1] : (((unsigned long long)pf[0].y << 32) | pf[0].x);
       // `longs`: bit i set iff days i..i+skip-1 are all hot (looking into the next word)
       unsigned long long longs = word;
       for (int k = 1; k < skip; ++k) longs &= (word >> k) | (nxt << (64 - k));
@@ -1185,6 +1207,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   const bool overlap = split && !(getenv("HDP_METRICS_OVERLAP") && atoi(getenv("HDP_METRICS_OVERLAP")) == 0);
   if (overlap && !plan->aux_stream) {
     HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream, hipStreamNonBlocking));
+    HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream2, hipStreamNonBlocking));
     HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
       HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_exceed[i], hipEventDisableTiming));
@@ -1192,10 +1215,13 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     }
   }
   // fork: the exceedance kernels run on the plan's stream, behind everything already queued on `stream`
+  // The state-machine kernels of odd batches run on a second plan stream, so that the workgroups of batch
+  // b + 1 fill the slots batch b frees while it drains (one of its waves runs for milliseconds).
   hipStream_t sx = overlap ? plan->aux_stream : stream;
   if (overlap) {
     HDP_HIP_TRY(hipEventRecord(plan->ev_fork, stream));
     HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_fork, 0));
+    HDP_HIP_TRY(hipStreamWaitEvent(plan->aux_stream2, plan->ev_fork, 0));
   }
   int64_t b = 0;
   for (int64_t c0 = 0; c0 < n_cells; c0 += batch, ++b) {
@@ -1210,6 +1236,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     const float *x_b = x_dev + c0 * int64_t(md.T);
     MetDev mb = md;
     mb.bits_g = md.bits_g + size_t(half) * size_t(batch) * (row_bytes / 8);
+    hipStream_t sm = (overlap && half) ? plan->aux_stream2 : stream;  // stream of this batch's state machine
     if (split) {
       // this half of the scratch is free once the state machine of batch b - 2 has read it
       if (overlap && b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_state[half], 0));
@@ -1217,7 +1244,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
       HDP_HIP_TRY(hipGetLastError());
       if (overlap) {
         HDP_HIP_TRY(hipEventRecord(plan->ev_exceed[half], sx));
-        HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->ev_exceed[half], 0));  // join (the last one closes the fork)
+        HDP_HIP_TRY(hipStreamWaitEvent(sm, plan->ev_exceed[half], 0));
       }
     }
     if (by_cells) {
@@ -1228,16 +1255,17 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
       const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
       HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
       const dim3 g((unsigned)blocks), t(kMetWaves * 64);
+      const size_t lds_c = size_t(kMetWaves) * 64 * kSlotPitch;
       switch (dg) {
-        case 1: hipLaunchKernelGGL(metrics_kernel_cells<1>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
-        case 2: hipLaunchKernelGGL(metrics_kernel_cells<2>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
-        case 3: hipLaunchKernelGGL(metrics_kernel_cells<3>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
-        case 4: hipLaunchKernelGGL(metrics_kernel_cells<4>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
-        case 5: hipLaunchKernelGGL(metrics_kernel_cells<5>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
-        default: hipLaunchKernelGGL(metrics_kernel_cells<6>, g, t, 0, stream, mb, is_south_dev + c0, nc, out_dev); break;
+        case 1: hipLaunchKernelGGL(metrics_kernel_cells<1>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
+        case 2: hipLaunchKernelGGL(metrics_kernel_cells<2>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
+        case 3: hipLaunchKernelGGL(metrics_kernel_cells<3>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
+        case 4: hipLaunchKernelGGL(metrics_kernel_cells<4>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
+        case 5: hipLaunchKernelGGL(metrics_kernel_cells<5>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
+        default: hipLaunchKernelGGL(metrics_kernel_cells<6>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
       }
       HDP_HIP_TRY(hipGetLastError());
-      if (overlap) HDP_HIP_TRY(hipEventRecord(plan->ev_state[half], stream));
+      if (overlap) HDP_HIP_TRY(hipEventRecord(plan->ev_state[half], sm));
       continue;
     }
     // (percentile, definition)-per-lane kernels: rows of this batch into the scratch, then transpose
@@ -1247,6 +1275,8 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
     HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
     int16_t *rows = plan->rows_scratch.as<int16_t>();
+    sm = stream;  // one row scratch: these batches stay in order on the caller's stream
+    if (overlap) HDP_HIP_TRY(hipStreamWaitEvent(sm, plan->ev_exceed[half], 0));
     hipLaunchKernelGGL(kern_rows, dim3((unsigned)blocks), dim3(kMetWaves * 64), lds, stream, mb, x_b, thr_b, ntc_b,
                        is_south_dev + c0, nc, rows);
     HDP_HIP_TRY(hipGetLastError());
@@ -1255,6 +1285,11 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     hipLaunchKernelGGL(metrics_rows_to_cells_kernel, dim3((unsigned)((nc + 63) / 64), (unsigned)(4 * PD)), dim3(256),
                        tile, stream, rows, md.Y, nc, md.Ypitch, out_dev, n_cells, c0);
     HDP_HIP_TRY(hipGetLastError());
+  }
+  if (overlap) {  // join: everything the plan's streams did is ordered before what the caller queues next
+    HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->ev_exceed[0], 0));
+    if (b > 1) HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->ev_exceed[1], 0));
+    if (b > 1 && by_cells) HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->ev_state[1], 0));
   }
   return HDP_OK;
 }
