@@ -347,6 +347,27 @@ def test_metrics_long_min_duration_and_record_end():
     assert np.array_equal(got.astype(np.int64), want)
 
 
+@pytest.mark.parametrize("n_defs", [1, 5, 6, 7, 12])
+def test_metrics_series_per_lane_kernel_definition_passes(n_defs, monkeypatch):
+    """metrics_kernel_cells<DG>: every template width (1..6 definitions per lane) and more than six
+    definitions (two passes over the bit words); hemispheres alternate inside every wave (two passes per
+    wave), 131 series (two full waves + a ragged one); against the oracle and the pair-per-lane kernel."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(1000 + n_defs)
+    defs = [[int(rng.integers(0, 7)), int(rng.integers(0, 3)), int(rng.integers(0, 3))] for _ in range(n_defs)]
+    case = _random_metrics_case(500 + n_defs, 7, 131, 3, defs, trend=1.2)
+    want = c_oracle.metrics(*case)
+    got = core.compute_heatwave_metrics(*case)
+    assert np.array_equal(got.astype(np.int64), want)
+    monkeypatch.setenv("HDP_METRICS_CELLS", "0")
+    assert np.array_equal(core.compute_heatwave_metrics(*case), got)
+    monkeypatch.setenv("HDP_METRICS_BATCH", "50")   # three batches: both plan streams + the double buffer
+    monkeypatch.delenv("HDP_METRICS_CELLS")
+    assert np.array_equal(core.compute_heatwave_metrics(*case), got)
+    monkeypatch.setenv("HDP_METRICS_OVERLAP", "0")
+    assert np.array_equal(core.compute_heatwave_metrics(*case), got)
+
+
 def test_metrics_split_path_in_small_batches(monkeypatch):
     """Exceedance-scratch path forced into several batches (ragged last one), and the fused kernel."""
     case = _random_metrics_case(123, 5, 11, 4, [[3, 0, 0], [3, 1, 1], [4, 2, 2]], trend=1.0)
@@ -361,7 +382,8 @@ def test_metrics_split_path_in_small_batches(monkeypatch):
 def test_c2_full_size_cross_kernel_properties(monkeypatch):
     """BASELINE config 2 at FULL size (3650 d x 180 x 360 = 64800 cells, 10 percentiles x 6
     definitions), too big for the Python oracle: size-independent properties instead --
-      * the three independently written metrics kernels (split, fused, general) agree bit for bit;
+      * the four independently written metrics kernels (series per lane, (percentile, definition) per lane,
+        fused, general) agree bit for bit;
       * the plan-based threshold kernel agrees bit for bit with the literal-table kernel on a sample;
       * thresholds are non-decreasing in the percentile; HWF >= HWD >= HWA >= 0; HWN <= HWF;
         HWA == HWF // HWN;  all-zero where HWN == 0;
@@ -399,7 +421,10 @@ def test_c2_full_size_cross_kernel_properties(monkeypatch):
     monkeypatch.setenv("HDP_METRICS_GENERAL", "1")
     general = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
     monkeypatch.delenv("HDP_METRICS_GENERAL")
-    assert np.array_equal(split, fused) and np.array_equal(split, general)
+    monkeypatch.setenv("HDP_METRICS_CELLS", "0")
+    pairs = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
+    monkeypatch.delenv("HDP_METRICS_CELLS")
+    assert np.array_equal(split, fused) and np.array_equal(split, general) and np.array_equal(split, pairs)
     hwf, hwn, hwd, hwa = (split[:, :, :, i, :].astype(np.int64) for i in range(4))
     assert hwf.min() >= 0 and np.all(hwf >= hwd) and np.all(hwd >= hwa) and np.all(hwn <= hwf)
     assert np.array_equal(hwa, np.where(hwn > 0, hwf // np.maximum(hwn, 1), 0))
