@@ -40,8 +40,13 @@ struct ThrDev {
   int SL, n_merge;                             // pitch of tix (8 * lanes per column); merging waves
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
-  int debug;  // timing ablations only (HDP_THR_DEBUG): 1 = no merge, 2 = no sort, 4 = no load, 8 = phase clocks
-  unsigned long long *clk;  // [4] accumulated s_memtime ticks of wave 0: load, sort, merge, blocks (debug & 8)
+  // Timing ablations and instrumentation only (HDP_THR_DEBUG, a bit mask; results are wrong under 1, 2, 4):
+  //   1 no merge, 2 no sort, 4 no sample loads, 8 phase clocks of the one-workgroup-per-cell kernel (forces it),
+  //   32 phase clocks of the pipelined kernel (merging wave / first producer), 512 with 32: start-up and step
+  //   loop of the merge instead of the producer phases, 64 roles by wave number instead of by SIMD,
+  //   4096 print the kernel variant chosen.  The clocks cost about 10 % and serialise on global atomics.
+  int debug;
+  unsigned long long *clk;  // [8] accumulated s_memtime ticks (debug & 8, debug & 32)
 };
 
 constexpr int kThrThreads = 512;  // 8 waves: all of them load and sort, ceil(rows/64) of them merge
