@@ -301,21 +301,25 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
                                                      const double *__restrict__ thr, int64_t n_thr_cells,
                                                      int64_t n_cells) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *thr32 = reinterpret_cast<float *>(smem);  // [P][n_doy_pad]
+  // thresholds as f32 rounded toward -inf, percentile-minor: [n_doy][PQ], PQ = P rounded up to kQB, so the kQB
+  // thresholds a lane needs for one day come with ONE 16-byte LDS read (address = day row, no per-percentile add)
+  float *thr32 = reinterpret_cast<float *>(smem);
+  const int PQ = (md.P + kQB - 1) / kQB * kQB;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t cell = blockIdx.x;
   {
     const double *tc = thr + (cell % n_thr_cells) * int64_t(md.n_doy) * md.P;
     for (int doy = threadIdx.x; doy < md.n_doy; doy += 256)
-      for (int q = 0; q < md.P; ++q)
-        thr32[q * md.n_doy_pad + doy] = f64_to_f32_down(tc[int64_t(q) * md.n_doy + doy]);
+      for (int q = 0; q < PQ; ++q)
+        thr32[doy * PQ + q] = f64_to_f32_down(tc[int64_t(min(q, md.P - 1)) * md.n_doy + doy]);
   }
   __syncthreads();
   const float *xc = x + cell * int64_t(md.T);
   const int n_words = (md.T + 63) >> 6;
   const int Tp = n_words * 64;
   unsigned long long *brow = md.bits_g + cell * md.P * int64_t(md.words_pad);
+  static_assert(kQB == 4, "one float4 of thresholds per day");
   for (int w0 = wave * kCW; w0 < n_words; w0 += 4 * kCW) {
     float xr[kCW];
     uint32_t dr[kCW / 2];
@@ -333,36 +337,27 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
     }
     for (int q0 = 0; q0 < md.P; q0 += kQB) {
       uint32_t lo[kQB], hi[kQB];
-      int roff[kQB];
 #pragma unroll
-      for (int j = 0; j < kQB; ++j) {
-        lo[j] = hi[j] = 0;
-        roff[j] = min(q0 + j, md.P - 1) * md.n_doy_pad;
-      }
-      float tc[kQB], tn[kQB];
-      {
-        const float *tp = thr32 + (dr[0] & 0xffffu);
-#pragma unroll
-        for (int j = 0; j < kQB; ++j) tc[j] = tp[roff[j]];
-      }
+      for (int j = 0; j < kQB; ++j) lo[j] = hi[j] = 0;
+      const float4 *t4 = reinterpret_cast<const float4 *>(thr32 + q0);  // row pitch PQ / 4 float4s
+      const int pq4 = PQ / 4;
+      float4 tc = t4[(dr[0] & 0xffffu) * pq4], tn = tc;
 #pragma unroll
       for (int w = 0; w < kCW; ++w) {
         if (w + 1 < kCW) {
           const int dn = ((w + 1) & 1) ? (dr[(w + 1) / 2] >> 16) : (dr[(w + 1) / 2] & 0xffffu);
-          const float *tp = thr32 + dn;
-#pragma unroll
-          for (int j = 0; j < kQB; ++j) tn[j] = tp[roff[j]];
+          tn = t4[dn * pq4];
         }
         const float xv = xr[w];
+        const float tj[kQB] = {tc.x, tc.y, tc.z, tc.w};
 #pragma unroll
         for (int j = 0; j < kQB; ++j) {
-          const unsigned long long m = __ballot(xv > tc[j]);
+          const unsigned long long m = __ballot(xv > tj[j]);
           asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
                        : "+v"(lo[j]), "+v"(hi[j])
                        : "s"((uint32_t)m), "s"((uint32_t)(m >> 32)), "i"(w));
         }
-#pragma unroll
-        for (int j = 0; j < kQB; ++j) tc[j] = tn[j];
+        tc = tn;
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -1194,7 +1189,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     if (rc != HDP_OK) return rc;
   }
   md.bits_g = plan->bits_scratch.as<unsigned long long>();
-  const size_t lds_a = (size_t(md.P) * md.n_doy_pad * 4 + 15) & ~size_t(15);
+  const size_t lds_a = (size_t((md.P + kQB - 1) / kQB * kQB) * md.n_doy * 4 + 15) & ~size_t(15);
   if (split) {
     HDP_REQUIRE(lds_a <= kLdsPerCU - 1024, HDP_EUNSUP, "too many percentiles for the exceedance kernel");
     HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(exceed_kernel),
