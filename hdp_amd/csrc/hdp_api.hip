@@ -345,6 +345,11 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
     for (int64_t y = 0; y + 1 < Y; ++y)
       if (ss[h * Y + y + 1].x - ss[h * Y + y].y < dmax + 64) uniform = false;
   pl->uniform_seasons = uniform;
+  bool fit16 = true;
+  for (int64_t d = 0; d < D; ++d)
+    fit16 = fit16 && dd[3 * d] >= 0 && dd[3 * d] <= 16383 && dd[3 * d + 1] >= 0 && dd[3 * d + 1] <= 16383 &&
+            dd[3 * d + 2] >= 0;
+  pl->defs_fit16 = fit16;
   hipError_t e = pl->doy_map.upload(dm.data(), dm.size() * 2);
   if (e == hipSuccess) e = pl->defs.upload(dd.data(), dd.size() * 4);
   if (e == hipSuccess) e = pl->seasons.upload(ss.data(), ss.size() * sizeof(int2));

@@ -110,6 +110,7 @@ struct hdp_metrics_plan {
   int64_t Ypitch = 0;
   int64_t dmax = 1;           // max over definitions of max(min_duration, 1)
   bool uniform_seasons = false;  // consecutive seasons >= dmax + 64 days apart (fast kernel)
+  bool defs_fit16 = false;       // every min_duration and max_break in [0, 16383], max_subs >= 0: packed 16-bit state machines
   hdp::DevBuf doy_map;   // uint16 [T rounded up to 64]
   hdp::DevBuf defs;      // int32 [D][3]
   hdp::DevBuf seasons;   // int2 [2][Y]  (north, south)

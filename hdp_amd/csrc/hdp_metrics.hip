@@ -809,6 +809,219 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
+// ---- the same kernel with the definitions' state as packed 16-bit pairs (two definitions per register) -----------
+// Eligible when every min_duration and max_break is <= 16383 and T <= 65535 (host-checked): run lengths and gaps
+// are clamped to 32767 (exact against operands <= 16383), sub-event counts cannot reach 32767, ids matter only through
+// equality within a season (mod 65536 is exact below 65536 heatwaves) and season sums are < 32768 by the plan's own
+// check.  Predicates are 0 / 0xffff half-words made with v_pk_sub_i16 + v_pk_ashrrev_i16 and combined with and / or /
+// bfi, so one instruction steps two state machines: about 7 instead of 12 vector instructions per definition and run.
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk_of(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_dup(int v) { return uint32_t(v) * 0x10001u; }       // v in [0, 65535] in both halves
+__device__ __forceinline__ uint32_t pk_lt(uint32_t a, uint32_t b) {                        // halves in [0, 32767]: a < b ? 0xffff : 0
+  return pk_bits((pk_of(a) - pk_of(b)) >> (short)15);
+}
+__device__ __forceinline__ uint32_t pk_nz(uint32_t x) {                                    // any 16-bit half: != 0 ? 0xffff : 0
+  const pk16 v = pk_of(x);
+  return pk_bits((v | (pk16)(0 - v)) >> (short)15);
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_bits(pk_of(a) + pk_of(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_bits(pk_of(a) - pk_of(b)); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+  return pk_bits(__builtin_elementwise_max(pk_of(a), pk_of(b)));
+}
+__device__ __forceinline__ uint32_t bsel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+
+struct CPair {  // two definitions' state, one per 16-bit half
+  uint32_t hw, subs, id;  // hw: 0xffff while a heatwave is active
+  uint32_t hwf, hwn, hwd, cur, last_id;
+};
+
+template <int NP>
+__global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 5))) void metrics_kernel_cells16(
+    MetDev md, const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
+  constexpr int DG = 2 * NP;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_dpass = (md.D + DG - 1) / DG;
+  const int64_t n_grp = (n_cells + 63) >> 6;
+  const int64_t task = int64_t(blockIdx.x) * kMetWaves + wave;
+  if (task >= n_grp * md.P * n_dpass) return;  // no workgroup barriers in this kernel
+  const int d0 = int(task % n_dpass) * DG;
+  const int p = int((task / n_dpass) % md.P);
+  const int64_t cell = (task / (int64_t(n_dpass) * md.P)) * 64 + lane;
+  const bool valid = cell < n_cells;
+  const int my_hemi = valid ? int(is_south[cell]) : 2;
+  const unsigned long long *brow = md.bits_g + ((valid ? cell : 0) * md.P + p) * int64_t(md.words_pad);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *slot = smem + (size_t(wave) * 64 + lane) * kSlotPitch;
+  uint4 *slot4 = reinterpret_cast<uint4 *>(slot);
+  const unsigned long long *slot8 = reinterpret_cast<const unsigned long long *>(slot);
+
+  // definition parameters of this pass, packed (wave-uniform); slots past D never label and are not stored
+  uint32_t min_dur[NP], max_break[NP], max_subs[NP];
+  int mmin = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    uint32_t a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      const int d = d0 + 2 * k + hlf;
+      const bool real = d < md.D;
+      const int md_ = real ? md.defs[d * 3 + 0] : 32767;
+      const int mb_ = real ? md.defs[d * 3 + 1] : 0;
+      const int ms_ = real ? min(md.defs[d * 3 + 2], 32767) : 0;
+      a |= uint32_t(md_) << (16 * hlf);
+      b |= uint32_t(mb_) << (16 * hlf);
+      c |= uint32_t(max(ms_, 0)) << (16 * hlf);
+      if (real) mmin = min(mmin, max(md_, 1));
+    }
+    min_dur[k] = a; max_break[k] = b; max_subs[k] = c;
+  }
+  const int skip = min(mmin, 64);  // look-ahead of the run-skip shortcut is one 64-day word
+  const int Y = md.Y, dmax = md.dmax;
+  const int n_words = (md.T + 63) >> 6;
+  const int64_t n_total = md.out_cells;
+  const int64_t plane = int64_t(Y) * n_total;
+
+  for (int h = 0; h < 2; ++h) {  // lanes of one hemisphere at a time: season bounds stay wave-uniform
+    const bool act = my_hemi == h;
+    if (__ballot(act) == 0) continue;
+    const int2 *seas = md.seasons + (h ? Y : 0);
+    int si = 0;
+    int sa = 0x7fffffff - 1024, sb = 0x7fffffff - 1024;
+    if (Y > 0) {
+      sa = __builtin_amdgcn_readfirstlane(seas[0].x);
+      sb = __builtin_amdgcn_readfirstlane(seas[0].y);
+    }
+    CPair st[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) st[k] = CPair{0, 0, 0, 0, 0, 0, 0, 0};
+    int open = 0, s_open = 0, e_prev = -(1 << 30);
+
+    // `lab`: 0xffff in the halves whose definition labels the run; days > 0 of it fall inside the current season
+    auto credit_k = [&](CPair &c, uint32_t lab, uint32_t run_id, int days) {
+      const uint32_t dd = pk_dup(days) & lab;
+      const uint32_t first = lab & pk_nz(run_id ^ c.last_id);
+      c.hwf = pk_add(c.hwf, dd);
+      c.hwn = pk_sub(c.hwn, first);  // first is -1 per half: += 1
+      c.cur = pk_add(c.cur & ~first, dd);
+      c.last_id = bsel(lab, run_id, c.last_id);
+      c.hwd = pk_max(c.hwd, c.cur);
+    };
+    // one finished run [s, e): reference state machine + season credit, for every definition of the pass
+    auto close_run = [&](int s, int e, bool may_credit) {
+      const uint32_t len = pk_dup(min(e - s, 32767));
+      const int days = may_credit ? min(e, sb) - max(s, sa) : 0;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        CPair &c = st[k];
+        const uint32_t ge = ~pk_lt(len, min_dur[k]);
+        const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
+        const uint32_t label = sub | ge;
+        c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), c.subs & ~c.hw);
+        c.id = pk_sub(c.id, ge & ~sub);  // += 1 where a new heatwave starts
+        c.hw = label;
+        if (days > 0) credit_k(c, label, c.id, days);
+      }
+    };
+    // close season si (wave-uniform) for every lane and definition
+    auto finalize = [&](bool credit_open) {
+      const bool pre = credit_open && open && s_open < sb;
+      const int pre_days = sb - max(s_open, sa);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        CPair &c = st[k];
+        if (pre) {
+          // a run still open dmax days past the season's end is labelled in every branch of the reference
+          const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
+          credit_k(c, 0xffffffffu, pk_sub(c.id, ~sub), pre_days);  // id + 1 unless it continues as a sub-event
+        }
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+          const int d = d0 + 2 * k + hlf;
+          if (act && d < md.D) {
+            const unsigned hwf = (c.hwf >> (16 * hlf)) & 0xffffu, hwn = (c.hwn >> (16 * hlf)) & 0xffffu;
+            const unsigned hwd = (c.hwd >> (16 * hlf)) & 0xffffu;
+            const unsigned hwa = hwn ? hwf / hwn : 0u;  // == HWF // HWN
+            int16_t *o = out + ((int64_t(p) * md.D + d) * Y + si) * n_total + md.cell_off + cell;
+            const int64_t mstride = int64_t(md.P) * md.D * plane;
+            o[0] = (int16_t)hwf;
+            o[mstride] = (int16_t)hwn;
+            o[2 * mstride] = (int16_t)hwd;
+            o[3 * mstride] = (int16_t)hwa;
+          }
+        }
+        c.hwf = c.hwn = c.hwd = c.cur = 0;
+        c.last_id = 0;
+      }
+      si += 1;
+      if (si < Y) {
+        sa = __builtin_amdgcn_readfirstlane(seas[si].x);
+        sb = __builtin_amdgcn_readfirstlane(seas[si].y);
+      } else {
+        sa = sb = 0x7fffffff - 1024;
+      }
+    };
+
+    const uint4 *bline = reinterpret_cast<const uint4 *>(brow);
+    uint4 pf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pf[q] = act ? bline[q] : make_uint4(0, 0, 0, 0);
+    for (int w = 0; w < n_words; ++w) {
+      const int t0 = w * 64;
+      if ((w & 7) == 0) {  // wave-uniform: park the fetched block, request the next one
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slot4[q] = pf[q];
+        const bool more = act && (w + 8 < md.words_pad);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pf[q] = more ? bline[(w >> 1) + 4 + q] : make_uint4(0, 0, 0, 0);
+      }
+      while (si < Y && sb + dmax <= t0) finalize(true);  // wave-uniform
+      const unsigned long long word = slot8[w & 7];
+      const unsigned long long nxt =
+          (w & 7) != 7 ? slot8[(w & 7) + 1] : (((unsigned long long)pf[0].y << 32) | pf[0].x);
+      unsigned long long longs = word;
+      for (int k = 1; k < skip; ++k) longs &= (word >> k) | (nxt << (64 - k));
+      uint32_t any_hw = 0;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) any_hw |= st[k].hw;
+      const bool work = open ? (word != ~0ull) : ((any_hw ? word : longs) != 0ull);
+      if (__ballot(work) == 0) continue;
+      const bool may_credit = t0 + 64 > sa;  // wave-uniform; the current season is never one already closed
+      int pos = 0;  // < 64 whenever it is used as a shift
+      while (true) {
+        if (!open) {
+          const unsigned long long r = (any_hw ? word : longs) >> pos;
+          if (r == 0) break;
+          pos += __builtin_ctzll(r);
+          s_open = t0 + pos;
+          open = 1;
+          const uint32_t gap = pk_dup(min(s_open - e_prev, 32767));  // >= 1
+#pragma unroll
+          for (int k = 0; k < NP; ++k) st[k].hw &= ~pk_lt(max_break[k], gap);  // metric.py:48-49
+        }
+        const unsigned long long rz = (~word) >> pos;
+        if (rz == 0) break;  // the run continues into the next word
+        pos += __builtin_ctzll(rz);
+        const int e = t0 + pos;
+        open = 0;
+        close_run(s_open, e, may_credit);
+        e_prev = e;
+        any_hw = 0;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) any_hw |= st[k].hw;
+      }
+    }
+    if (open) {  // a run reaching the end of the record closes at T (metric.py:27: zero padding)
+      close_run(s_open, md.T, true);
+      open = 0;
+    }
+    while (si < Y) finalize(false);
+  }
+}
+
 // Row layout of the (percentile, definition)-per-lane kernels, [planes][nc][Ypitch], -> device layout
 // [planes][Y][n_total] at series offset cell_off.  One workgroup per (plane, 64 series), through LDS.
 __global__ __launch_bounds__(256) void metrics_rows_to_cells_kernel(const int16_t *__restrict__ src, int Y, int64_t nc,
@@ -1149,6 +1362,9 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   const bool uniform = plan->uniform_seasons && !getenv("HDP_METRICS_GENERAL");
   const bool split = uniform && !getenv("HDP_METRICS_FUSED");
   const bool by_cells = split && !(getenv("HDP_METRICS_CELLS") && atoi(getenv("HDP_METRICS_CELLS")) == 0);
+  // packed 16-bit state machines (two definitions per register) when the definitions and the record allow
+  const bool pk_ok = by_cells && plan->defs_fit16 && plan->T <= 65535 &&
+                     !(getenv("HDP_METRICS_PACKED") && atoi(getenv("HDP_METRICS_PACKED")) == 0);
   const size_t seas_bytes = uniform ? 0 : ((size_t(2) * md.Y * sizeof(int2) + 15) & ~size_t(15));
   const size_t thr_bytes = split ? 0 : ((size_t(md.np_max) * md.n_doy_pad * 4 + 15) & ~size_t(15));
   const size_t per_wave = thr_bytes + size_t(md.np_max) * (uniform ? kRow : kChunkWords) * 8;
@@ -1245,12 +1461,19 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     if (by_cells) {
       mb.out_cells = n_cells;  // the device layout is indexed with the series of the whole call
       mb.cell_off = c0;
-      const int dg = md.D <= 6 ? md.D : 6;
+      const int dg = pk_ok ? (md.D <= 6 ? ((md.D + 1) & ~1) : 6) : (md.D <= 6 ? md.D : 6);
       const int64_t tasks = ((nc + 63) / 64) * md.P * ((md.D + dg - 1) / dg);
       const int64_t blocks = (tasks + kMetWaves - 1) / kMetWaves;
       HDP_REQUIRE(blocks < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
       const dim3 g((unsigned)blocks), t(kMetWaves * 64);
       const size_t lds_c = size_t(kMetWaves) * 64 * kSlotPitch;
+      if (pk_ok) {
+        switch (dg) {
+          case 2: hipLaunchKernelGGL(metrics_kernel_cells16<1>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
+          case 4: hipLaunchKernelGGL(metrics_kernel_cells16<2>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
+          default: hipLaunchKernelGGL(metrics_kernel_cells16<3>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
+        }
+      } else
       switch (dg) {
         case 1: hipLaunchKernelGGL(metrics_kernel_cells<1>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
         case 2: hipLaunchKernelGGL(metrics_kernel_cells<2>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
