@@ -368,6 +368,26 @@ def test_metrics_series_per_lane_kernel_definition_passes(n_defs, monkeypatch):
     assert np.array_equal(core.compute_heatwave_metrics(*case), got)
 
 
+def test_metrics_packed_and_unpacked_state_machines(monkeypatch):
+    """The series-per-lane kernel keeps two definitions per register as 16-bit halves when every min_duration and
+    max_break is <= 16383 (and T <= 65535); otherwise 32-bit state.  Same results, including at the limit, with an
+    odd number of definitions (a padding half), max_subs beyond 16 bits and a long always-hot stretch."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(4242)
+    base_defs = [[3, 0, 0], [3, 1, 1], [1, 2, 100000], [0, 0, 1], [7, 3, 2]]
+    case = list(_random_metrics_case(321, 9, 97, 4, base_defs, trend=1.5))
+    case[0][5, 400:1900] = 50.0                      # one series: a 1500-day run
+    want = c_oracle.metrics(*case)
+    got = core.compute_heatwave_metrics(*case)
+    assert np.array_equal(got.astype(np.int64), want)
+    monkeypatch.setenv("HDP_METRICS_PACKED", "0")
+    assert np.array_equal(core.compute_heatwave_metrics(*case), got)
+    monkeypatch.delenv("HDP_METRICS_PACKED")
+    for edge in ([[16383, 0, 0], [3, 16383, 1]], [[16384, 0, 0], [3, 1, 1]], [[3, 16384, 2]]):
+        case[3] = edge
+        assert np.array_equal(core.compute_heatwave_metrics(*case).astype(np.int64), c_oracle.metrics(*case))
+
+
 def test_metrics_split_path_in_small_batches(monkeypatch):
     """Exceedance-scratch path forced into several batches (ragged last one), and the fused kernel."""
     case = _random_metrics_case(123, 5, 11, 4, [[3, 0, 0], [3, 1, 1], [4, 2, 2]], trend=1.0)
