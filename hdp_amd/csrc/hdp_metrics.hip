@@ -839,7 +839,7 @@ struct CPair {  // two definitions' state, one per 16-bit half
 };
 
 template <int NP>
-__global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 5))) void metrics_kernel_cells16(
+__global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 4))) void metrics_kernel_cells16(
     MetDev md, const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
   constexpr int DG = 2 * NP;
   const int lane = threadIdx.x & 63;
