@@ -1316,8 +1316,26 @@ int64_t metrics_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells, int64
   return std::min<int64_t>(batch, n_cells);
 }
 
+// streams and events of the split path (created once per plan; also by hdp_metrics_plan_reserve, so that a
+// later hdp_metrics_f32_dev creates nothing)
+static int ensure_plan_streams(const hdp_metrics_plan *plan) {
+  if (plan->aux_stream) return HDP_OK;
+  HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream, hipStreamNonBlocking));
+  HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream2, hipStreamNonBlocking));
+  HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) {
+    HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_exceed[i], hipEventDisableTiming));
+    HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_state[i], hipEventDisableTiming));
+  }
+  return HDP_OK;
+}
+
 int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells) {
   if (!plan->uniform_seasons || n_cells <= 0) return HDP_OK;
+  {
+    const int rc = ensure_plan_streams(plan);
+    if (rc != HDP_OK) return rc;
+  }
   const int64_t words_pad = ((((plan->T + 63) >> 6) + kCW - 1) / kCW) * kCW;
   const size_t need = 2 * size_t(metrics_batch_cells(plan, n_cells, n_cells)) * size_t(plan->P) * words_pad * 8;
   if (plan->bits_scratch.bytes < need) {
@@ -1416,14 +1434,9 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_rows),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const bool overlap = split && !(getenv("HDP_METRICS_OVERLAP") && atoi(getenv("HDP_METRICS_OVERLAP")) == 0);
-  if (overlap && !plan->aux_stream) {
-    HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream, hipStreamNonBlocking));
-    HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream2, hipStreamNonBlocking));
-    HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) {
-      HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_exceed[i], hipEventDisableTiming));
-      HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_state[i], hipEventDisableTiming));
-    }
+  if (overlap) {
+    const int rc = ensure_plan_streams(plan);
+    if (rc != HDP_OK) return rc;
   }
   // fork: the exceedance kernels run on the plan's stream, behind everything already queued on `stream`
   // The state-machine kernels of odd batches run on a second plan stream, so that the workgroups of batch
