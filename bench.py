@@ -30,14 +30,21 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 HBM_COPY_GBS = 6290.0       # measured float4 copy ceiling, same table
 
-CONFIGS = {
-    # name: (years, n_lat, n_lon)
-    "c3": (100, 720, 1440),   # BASELINE.json configs[2]: 36500 d x 720 x 1440, the config the target is quoted on
-    "c2": (10, 180, 360),     # configs[1]: 3650 d x 180 x 360
-    "tiny": (10, 16, 32),
-}
 PERCENTILES = np.arange(0.9, 1.0, 0.01)                                   # 10 (README.md:48)
 DEFINITIONS = [[3, 0, 0], [3, 1, 1], [4, 0, 0], [4, 1, 1], [5, 0, 0], [5, 1, 1]]  # 6 (README.md:51)
+# configs[4] names only the counts (20 percentiles x 12 definitions); these values are this build's choice
+PERCENTILES_C5 = np.linspace(0.80, 0.99, 20)
+DEFINITIONS_C5 = [[d, b, b] for d in (3, 4, 5, 6) for b in (0, 1, 2)]
+CONFIGS = {
+    # name: (years, n_lat, n_lon, ensemble members, percentiles, definitions)
+    "c3": (100, 720, 1440, 1, PERCENTILES, DEFINITIONS),  # BASELINE.json configs[2], the config the target is quoted on
+    "c2": (10, 180, 360, 1, PERCENTILES, DEFINITIONS),    # configs[1]: 3650 d x 180 x 360
+    # configs[4]: 10 members x 36500 d x 192 x 288; members are concatenated along time for the thresholds
+    # (threshold.py:114-119) and share their cell's thresholds in the metrics pass
+    "c5": (100, 192, 288, 10, PERCENTILES_C5, DEFINITIONS_C5),
+    "tiny": (10, 16, 32, 1, PERCENTILES, DEFINITIONS),
+    "tiny5": (10, 8, 16, 3, PERCENTILES_C5, DEFINITIONS_C5),
+}
 
 
 def main():
@@ -80,24 +87,24 @@ def main():
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    years, n_lat, n_lon = CONFIGS[args.config]
+    years, n_lat, n_lon, M, PERCENTILES, DEFINITIONS = CONFIGS[args.config]
     T = years * 365
     cells_rank = args.cells if args.cells > 0 else n_lat * n_lon   # weak scaling: full grid per rank
     P, D = PERCENTILES.size, len(DEFINITIONS)
 
     # ---- host tables (the reference builds the same ones in Python: threshold.py:125, metric.py:410-416)
     dates = utils.noleap_date_range("2000-01-01", f"{2000 + years - 1}-12-31")
-    time_index, cols = cal.window_columns(dates, 7)
+    time_index, cols = cal.window_columns(np.concatenate([dates] * M), 7)   # [n_doy, M * years]
     doy_map = cal.build_doy_map(dates)
     north, south, season_years = cal.hemisphere_season_tables(dates)
     Y = north.shape[0]
     n_doy = time_index.shape[0]
-    tplan = core.ThresholdPlan(time_index, cols, PERCENTILES, T)
+    tplan = core.ThresholdPlan(time_index, cols, PERCENTILES, M * T)
     mplan = core.MetricsPlan(doy_map, n_doy, DEFINITIONS, north, south, P)
     Yp = mplan.year_pitch
 
     # ---- bands: the largest equal split of this rank's cells whose buffers fit in HBM ----------------
-    per_cell = 2 * T * 4 + n_doy * P * 8 + 4 * P * D * Yp * 2 + 4 + 1
+    per_cell = 2 * M * T * 4 + n_doy * P * 8 + M * (4 * P * D * Yp * 2 + 1) + 4
     free_b, total_b = torch.cuda.mem_get_info(dev)
     budget = int(free_b * args.mem_fraction)
     n_bands = 1
@@ -109,29 +116,30 @@ def main():
     def raw(nbytes):
         return torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
 
-    xb, xm = raw(bc * T * 4), raw(bc * T * 4)
+    # baseline [cell][M * T] (members appended along time); measure [member][cell][T] = M * bc series
+    xb, xm = raw(bc * M * T * 4), raw(M * bc * T * 4)
     thr = raw(bc * n_doy * P * 8)
-    out = torch.empty(4 * P * D * bc * Yp, dtype=torch.int16, device=dev)
+    out = torch.empty(4 * P * D * M * bc * Yp, dtype=torch.int16, device=dev)
     # latitude of every cell of this rank's grid, row-major (lat, lon); band b owns cells [b*bc, (b+1)*bc)
     lat_axis = np.linspace(-90.0, 90.0, n_lat)
     cell_ids = np.arange(cells_rank_eff) % (n_lat * n_lon)
     lat_cells = lat_axis[cell_ids // n_lon].astype(np.float32)
-    lat_dev = torch.from_numpy(lat_cells[:bc].copy()).to(dev)
-    south_dev = [torch.from_numpy((lat_cells[b * bc:(b + 1) * bc] < 0).astype(np.uint8)).to(dev)
+    lat_dev = torch.from_numpy(np.tile(lat_cells[:bc], M)).to(dev)
+    south_dev = [torch.from_numpy(np.tile((lat_cells[b * bc:(b + 1) * bc] < 0).astype(np.uint8), M)).to(dev)
                  for b in range(n_bands)]
 
     # synthetic inputs, generated on the device (reference generator formula + hashed noise):
     # baseline = control, measure = control + warming trend (hdp/utils.py:41: t / (365*100))
     seed = 0
-    _lib.check(lib.hdp_generate_series_dev(xb.data_ptr(), bc, T, rank * cells_rank_eff, lat_dev.data_ptr(),
+    _lib.check(lib.hdp_generate_series_dev(xb.data_ptr(), bc, M * T, rank * cells_rank_eff, lat_dev.data_ptr(),
                                            seed, 0.7, 0.0, stream))
-    _lib.check(lib.hdp_generate_series_dev(xm.data_ptr(), bc, T, rank * cells_rank_eff, lat_dev.data_ptr(),
+    _lib.check(lib.hdp_generate_series_dev(xm.data_ptr(), M * bc, T, rank * cells_rank_eff * M, lat_dev.data_ptr(),
                                            seed + 1, 0.7, 1.0 / 36500.0, stream))
     torch.cuda.synchronize(dev)
 
     import ctypes
     n_ev_steps = args.steps
-    mplan.reserve(bc)   # exceedance scratch allocated before anything is timed
+    mplan.reserve(M * bc)   # exceedance scratch allocated before anything is timed
     ev = [[[lib.hdp_event_create() for _ in range(3)] for _ in range(n_bands)] for _ in range(n_ev_steps)]
     t_thr, t_met = [], []
 
@@ -143,7 +151,7 @@ def main():
             tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
             if k >= 0:
                 lib.hdp_event_record(ev[k][b][1], stream)
-            mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[b].data_ptr(), bc, out.data_ptr(), stream)
+            mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[b].data_ptr(), M * bc, out.data_ptr(), stream)
             if k >= 0:
                 lib.hdp_event_record(ev[k][b][2], stream)
 
@@ -172,20 +180,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
-    cell_days_step = 2.0 * cells_rank_eff * T * world   # thresholds pass + metrics pass, all ranks
+    cell_days_step = 2.0 * cells_rank_eff * M * T * world   # thresholds pass + metrics pass, all ranks
     value = cell_days_step / (ms_per_step * 1e-3)
 
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch time --------
-    bytes_thr = bc * (4 * T + 8 * n_doy * P)
-    bytes_met = bc * (4 * T + 8 * n_doy * P + 2 * 4 * Y * P * D)          # int16 metrics
+    bytes_thr = bc * (4 * M * T + 8 * n_doy * P)
+    bytes_met = bc * (M * 4 * T + 8 * n_doy * P + M * 2 * 4 * Y * P * D)  # int16 metrics; thresholds shared by members
     ms_thr, ms_met = float(np.mean(t_thr)), float(np.mean(t_met))
     kern = {
         "thresholds_kernel": {"ms_per_launch": ms_thr, "algorithmic_bytes": bytes_thr,
                               "GBps": bytes_thr / ms_thr / 1e6, "frac_hbm": bytes_thr / ms_thr / 1e6 / HBM_PEAK_GBS,
-                              "cell_days_per_s": bc * T / (ms_thr * 1e-3)},
+                              "cell_days_per_s": bc * M * T / (ms_thr * 1e-3)},
         "metrics_kernel": {"ms_per_launch": ms_met, "algorithmic_bytes": bytes_met,
                            "GBps": bytes_met / ms_met / 1e6, "frac_hbm": bytes_met / ms_met / 1e6 / HBM_PEAK_GBS,
-                           "cell_days_per_s": bc * T / (ms_met * 1e-3)},
+                           "cell_days_per_s": bc * M * T / (ms_met * 1e-3)},
     }
     dom = "thresholds_kernel" if ms_thr >= ms_met else "metrics_kernel"
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process,
@@ -255,34 +263,36 @@ def main():
         from oracle import c_oracle
         cores = c_oracle.max_threads()
         win = cal.expand_window_table(time_index, cols)
-        xb_h = lambda n: xb[: n * T * 4].cpu().numpy().view(np.float32).reshape(n, T)  # noqa: E731
-        xm_h = lambda n: xm[: n * T * 4].cpu().numpy().view(np.float32).reshape(n, T)  # noqa: E731
+        xb_h = lambda n: xb[: n * M * T * 4].cpu().numpy().view(np.float32).reshape(n, M * T)  # noqa: E731
+        # the M members of the first n cells, member-major like the device buffer
+        xm_h = lambda n: (xm.view(torch.float32).view(M, bc, T)[:, :n].cpu().numpy()  # noqa: E731
+                          .reshape(M * n, T))
+        thr_m = lambda th: np.concatenate([th] * M)                                     # noqa: E731
+        hemi_m = lambda n: np.tile((lat_cells[:n] < 0).astype(np.uint8), M)             # noqa: E731
         n0 = min(bc, cores)
         tc = time.perf_counter()
         th0 = c_oracle.thresholds(xb_h(n0), win, PERCENTILES)
-        hemi0 = (lat_cells[:n0] < 0).astype(np.uint8)
-        c_oracle.metrics(xm_h(n0), th0, doy_map, DEFINITIONS, north, south, hemi0)
+        c_oracle.metrics(xm_h(n0), thr_m(th0), doy_map, DEFINITIONS, north, south, hemi_m(n0))
         per_round = time.perf_counter() - tc
         rounds = int(max(1, min(64, args.cpu_seconds / max(per_round, 1e-3))))
         ns = min(bc, n0 * rounds)
         tc = time.perf_counter()
         th_cpu = c_oracle.thresholds(xb_h(ns), win, PERCENTILES)
-        hemi = (lat_cells[:ns] < 0).astype(np.uint8)
-        met_cpu = c_oracle.metrics(xm_h(ns), th_cpu, doy_map, DEFINITIONS, north, south, hemi)
+        met_cpu = c_oracle.metrics(xm_h(ns), thr_m(th_cpu), doy_map, DEFINITIONS, north, south, hemi_m(ns))
         cpu_s = time.perf_counter() - tc
         cpu = None if world > 1 else {   # reported at N = 1 only (torchrun pins OMP_NUM_THREADS=1)
-            "value": 2.0 * ns * T / cpu_s, "unit": "cell-days/s", "cores": cores, "kind": "port",
+            "value": 2.0 * ns * M * T / cpu_s, "unit": "cell-days/s", "cores": cores, "kind": "port",
                "sample": f"first {ns} cells of band 0 of the same workload (T={T}, P={P}, D={D}), both passes, "
                       f"{cpu_s:.1f} s; oracle/hdp_oracle.c (reference algorithm restated in C, OpenMP over cells)"}
         # the same sample doubles as a parity spot-check of what the timed kernels produced (band 0 flags)
         tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
-        mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[0].data_ptr(), bc, out.data_ptr(), stream)
+        mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[0].data_ptr(), M * bc, out.data_ptr(), stream)
         torch.cuda.synchronize(dev)
         # device layout [cell][P][n_doy] -> the reference's (cell, doy, percentile)
         th_gpu = thr[: ns * n_doy * P * 8].cpu().numpy().view(np.float64).reshape(ns, P, n_doy).transpose(0, 2, 1)
         # device layout [4][P][D][Y][series] -> the reference's (percentile, definition, series, metric, year)
-        out_gpu = out.view(4, P * D, Y, bc)[:, :, :, :ns].cpu().numpy()
-        met_gpu = np.transpose(out_gpu.reshape(4, P, D, Y, ns), (1, 2, 4, 0, 3)).astype(np.int64)
+        out_gpu = out.view(4, P * D, Y, M, bc)[..., :ns].cpu().numpy()
+        met_gpu = np.transpose(out_gpu.reshape(4, P, D, Y, M * ns), (1, 2, 4, 0, 3)).astype(np.int64)
         parity = {"cells": ns, "thresholds_bit_exact": bool(np.array_equal(th_gpu, th_cpu)),
                   "metrics_bit_exact": bool(np.array_equal(met_gpu, met_cpu))}
 
@@ -292,9 +302,9 @@ def main():
             "value": value, "unit": "cell-days/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {T} d x {n_lat} x {n_lon} fp32, {P} percentiles x {D} definitions, "
+            "config": {"workload": f"{args.config}: {f'{M} members x ' if M > 1 else ''}{T} d x {n_lat} x {n_lon} fp32, {P} percentiles x {D} definitions, "
                                    f"window radius 7, noleap, per GPU",
-                       "cells_per_gpu": int(cells_rank_eff), "T": T, "percentiles": P, "definitions": D,
+                       "cells_per_gpu": int(cells_rank_eff), "members": M, "T": T, "percentiles": P, "definitions": D,
                        "seasons": int(Y), "resident_bands_per_step": n_bands, "cells_per_band": int(bc),
                        "sharding": "independent grid cells per rank, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "pre_step": pre_step, "allgather": allgather,

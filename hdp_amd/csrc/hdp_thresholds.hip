@@ -38,6 +38,7 @@ struct ThrDev {
   const float *ninf;                 // four -inf words (what a slot without a sample loads)
   const int32_t *blk_grp_off, *grp_col;  // 16-byte gathers: first column of every group of four, per block
   int SL, n_merge;                             // pitch of tix (8 * lanes per column); merging waves
+  int select;                                  // one-workgroup-per-cell kernel: rank selection instead of the merge
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
   // Timing ablations and instrumentation only (HDP_THR_DEBUG, a bit mask; results are wrong under 1, 2, 4):
@@ -147,6 +148,50 @@ __device__ __forceinline__ void ce_reg(float &a, float &b) {  // larger value to
   const float hi = fmax_nn(a, b), lo = fmin_nn(a, b);
   a = hi;
   b = lo;
+}
+
+// ---- wave sorter for S > 128: one column of 64*EPL keys per wave, lane-major ---------------------
+// Element e = lane * EPL + r, so the log2(EPL) short distances of every merge are register-to-register
+// and only 21 of the 55 stages of a 1024-key sort cross lanes (45 with e = r * 64 + lane); of those,
+// lane xor 1, 2, 3, 4, 7, 8, 15 are DPP moves and only xor 16, 31, 63 go through ds_bpermute.
+// Same comparator network as bitonic_desc, so the sorted column is identical.
+template <int ML>
+__device__ __forceinline__ float lane_xor(float v) {
+  if constexpr (ML == 1 || ML == 2 || ML == 3 || ML == 4 || ML == 7 || ML == 15) return row_xor<ML>(v);
+  else if constexpr (ML == 8) return dpp_mov1<0x128>(v);  // row_ror:8
+  else return __shfl_xor(v, ML, 64);
+}
+template <int EPL, int MASK, int TOP>
+__device__ __forceinline__ void lm_stage(float (&v)[EPL], int lane) {
+  constexpr int MR = MASK & (EPL - 1), ML = MASK / EPL;
+  if constexpr (ML == 0) {
+#pragma unroll
+    for (int r = 0; r < EPL; ++r)
+      if ((r & TOP) == 0) ce_reg(v[r], v[r ^ MR]);
+  } else {
+    // +inf on lanes that keep the larger key, -inf on the others: med3 is then max or min
+    const float lim = (lane & (TOP / EPL)) ? -INFINITY : INFINITY;
+    float o[EPL];
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) o[r] = lane_xor<ML>(v[r ^ MR]);
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], o[r], lim);
+  }
+}
+template <int EPL, int J>
+__device__ __forceinline__ void lm_clean(float (&v)[EPL], int lane) {
+  if constexpr (J >= 1) {
+    lm_stage<EPL, J, J>(v, lane);
+    lm_clean<EPL, J / 2>(v, lane);
+  }
+}
+template <int EPL, int K = 2>
+__device__ __forceinline__ void bitonic_desc_lm(float (&v)[EPL], int lane) {
+  if constexpr (K <= 64 * EPL) {
+    lm_stage<EPL, K - 1, K / 2>(v, lane);  // mirrored first step of the merge
+    lm_clean<EPL, K / 4>(v, lane);         // half-cleaners
+    bitonic_desc_lm<EPL, 2 * K>(v, lane);
+  }
 }
 
 // cross-lane compare-exchange: partner lane = lane ^ XOR, partner register = MIRROR ? 7 - i : i
@@ -265,7 +310,7 @@ __device__ __forceinline__ void sort_column(float *col, int S, uint32_t *flag_ou
   uint32_t n_nan = 0, n_pos = 0, n_neg = 0;
 #pragma unroll
   for (int r = 0; r < EPL; ++r) {
-    const int e = r * 64 + lane;
+    const int e = lane * EPL + r;
     float x = (e < S) ? col[e] : -INFINITY;
     const bool is_nan = (x != x);
     const bool is_pos = (e < S) && (x == INFINITY);
@@ -275,10 +320,10 @@ __device__ __forceinline__ void sort_column(float *col, int S, uint32_t *flag_ou
     n_neg += __popcll(__ballot(is_neg));
     v[r] = is_nan ? 0.0f : x;
   }
-  bitonic_desc<EPL>(v, lane);
+  bitonic_desc_lm<EPL>(v, lane);
 #pragma unroll
   for (int r = 0; r < EPL; ++r) {
-    const int e = r * 64 + lane;
+    const int e = lane * EPL + r;
     if (e < S) col[e] = __int_as_float(f32_key(v[r]));
   }
   if (lane == 0) *flag_out = (n_nan ? 0x80000000u : 0u) | (n_pos << 15) | n_neg;
@@ -594,9 +639,130 @@ __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf
   merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
 }
 
-template <int EPL>
+// ---- rank selection (many samples per column) ---------------------------------------------------
+// The merge walks every order statistic down to the deepest requested rank, one lane per row: with
+// S = 1000 samples per column (a 10-member ensemble) that is 3000 dependent steps on the two dozen
+// lanes whose rows fit the LDS.  Here one lane owns one (row, requested rank) pair instead and finds
+// its order statistic directly in the window's W sorted columns:
+//   keep, per column j, an interval [lo_j, hi_j] around c_j = the number of its keys ranked above the
+//   wanted element; take the middle key of the widest interval as pivot, count by bisection inside
+//   every interval the keys ranked above the pivot (ties are ordered by column, then position, so
+//   the ranking is total), and move every lo_j or every hi_j to those counts depending on which side
+//   of the wanted rank the pivot fell.  The pivot's own interval at least halves each round.
+// When the intervals have closed, sum c_j = R and the R-th largest key is the best of the W heads
+// col_j[c_j + 1]; the (R + 1)-th is the runner-up of those heads and the winner's successor.
+// The adjacent pair (R, R + 1) is exactly what one interpolated quantile needs.
+template <int NC>
+__device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, const uint32_t *flags, int row0,
+                                            int nrows, int tid, int64_t cell, double *__restrict__ out) {
+  const int nt_all = pd.nt_top + pd.nt_bot;
+  const int S = pd.S, W = pd.W;
+  for (int task = tid; task < nrows * nt_all; task += kThrThreads) {
+    const int r = task % nrows, ti = task / nrows;
+    const bool top = ti < pd.nt_top;
+    const int2 t = top ? pd.tgt_top[ti] : pd.tgt_bot[ti - pd.nt_top];
+    const int p = t.y & 0xffff, kind = t.y >> 16;
+    const bool pair = (kind == E_TOP_PAIR) || (kind == E_BOT_PAIR);
+    // a = R-th largest (0-based), b = (R+1)-th largest.  Top list, rank k: best = k-th largest, prev = (k-1)-th;
+    // bottom list, rank k: best = k-th smallest = (n-1-k)-th largest, prev = (n-k)-th largest.
+    const int R = top ? (pair ? t.x - 1 : t.x) : (pd.n - 1 - t.x);
+    const uint16_t *cl = pd.cols_local + size_t(row0 + r) * W;
+
+    int base[NC], lo[NC], hi[NC];
+    RowFlags rf{0, 0};
+    uint32_t nan_or = 0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int c = (j < W) ? int(cl[j]) : 0;
+      const uint32_t f = (j < W) ? flags[c] : 0u;
+      nan_or |= f;
+      rf.n_pos += (f >> 15) & 0x7fff;
+      rf.n_neg += f & 0x7fff;
+      base[j] = c * pd.S_pad;
+      lo[j] = 0;
+      hi[j] = (j < W) ? S : 0;
+    }
+    if (nan_or >> 31) rf.n_pos = -1;
+
+    while (true) {
+      // widest interval -> pivot (its middle key: the pivot's own interval at least halves every round)
+      int wj = 0, ww = hi[0] - lo[0], wlo = lo[0], wbase = base[0];
+#pragma unroll
+      for (int j = 1; j < NC; ++j) {
+        const int w = hi[j] - lo[j];
+        const bool better = w > ww;
+        ww = better ? w : ww;
+        wj = better ? j : wj;
+        wlo = better ? lo[j] : wlo;
+        wbase = better ? base[j] : wbase;
+      }
+      if (ww <= 0) break;
+      const int mid = wlo + ((ww + 1) >> 1);  // in [lo + 1, hi]
+      const int pkey = colk[wbase + mid];
+      // Per column: c_j = number of keys ranked above the pivot.  lo_j <= c_j <= hi_j is known, so a
+      // descent in power-of-two strides from lo_j finds it without looking at hi_j: key > thr[j] is
+      // "ranked above the pivot" (an equal key of an earlier column ranks above it, of a later column
+      // below it); the pivot's own column and the padding columns never move.
+      int pos[NC], thr[NC];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const bool fixed = (j == wj) || (j >= W);
+        pos[j] = (j == wj) ? mid - 1 : lo[j];
+        thr[j] = fixed ? 0x7fffffff : pkey - ((j < wj) ? 1 : 0);
+      }
+      int nb = 11;  // strides 2^(nb-1) .. 1 cover every interval of the wave's lanes
+      while (nb > 0 && __ballot((ww >> (nb - 1)) != 0) == 0) --nb;
+      for (int sb = nb - 1; sb >= 0; --sb) {
+        const int stride = 1 << sb;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          const int idx = min(pos[j] + stride, S + 1);  // the sentinel after the column is never above
+          const int k = colk[base[j] + idx];
+          pos[j] = (k > thr[j]) ? idx : pos[j];
+        }
+      }
+      int G = 0;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) G += pos[j];
+      if (G == R) {  // the pivot is the wanted element
+#pragma unroll
+        for (int j = 0; j < NC; ++j) lo[j] = hi[j] = pos[j];
+      } else if (G > R) {  // pivot ranked below it: at most these many keys of each column are above it
+#pragma unroll
+        for (int j = 0; j < NC; ++j) hi[j] = pos[j];
+      } else {  // pivot ranked above it (so the pivot itself counts in its own column)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) lo[j] = pos[j] + ((j == wj) ? 1 : 0);
+      }
+    }
+
+    // heads after the R keys above the wanted one
+    int a = kKeyMin, b = kKeyMin, aj = 0, abase = base[0], apos = 0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int k = (j < W) ? colk[base[j] + lo[j] + 1] : kKeyMin;
+      const bool win = k > a;
+      b = win ? a : max(b, k);
+      aj = win ? j : aj;
+      abase = win ? base[j] : abase;
+      apos = win ? lo[j] + 1 : apos;
+      a = win ? k : a;
+    }
+    (void)aj;
+    if (pair) b = max(b, colk[abase + apos + 1]);  // R + 1 <= n - 1 for a pair: apos + 1 <= S + 1 (the sentinel)
+    const float fa = key_f32(a), fb = key_f32(b);
+    const QuantileParam qp = pd.qp[p];
+    const float q_hi = fa, q_lo = pair ? fb : fa;
+    out[cell * pd.n_doy * int64_t(pd.P) + size_t(p) * pd.n_doy + row0 + r] =
+        finish_quantile(qp, q_lo, q_hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
+  }
+}
+
+// SELECT: rank selection instead of the merge; its interval state wants more than 128 VGPRs, and the
+// deep-merge plans it serves fill the LDS with one workgroup per CU anyway (2 waves per SIMD).
+template <int EPL, bool SELECT>
 // second bound: 4 waves per SIMD = two 512-thread workgroups per CU (<= 128 VGPRs)
-__global__ __launch_bounds__(kThrThreads, 4) void thresholds_kernel(ThrDev pd, const float *__restrict__ x,
+__global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel(ThrDev pd, const float *__restrict__ x,
                                                                  int64_t n_cells,
                                                                  double *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -670,7 +836,13 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_kernel(ThrDev pd, c
 
     // 3. + 4. merge and interpolate, one lane per row; every quantile is stored as soon as its
     //         second order statistic comes out of the merge
-    if (tid < nrows) {
+    if constexpr (SELECT) {
+      const int *colk = reinterpret_cast<const int *>(colbuf);
+      if (pd.debug & 1) {
+      } else if (pd.W <= 4) select_rows<4>(pd, colk, flags, row0, nrows, tid, cell, out);
+      else if (pd.W <= 8) select_rows<8>(pd, colk, flags, row0, nrows, tid, cell, out);
+      else select_rows<16>(pd, colk, flags, row0, nrows, tid, cell, out);
+    } else if (tid < nrows) {
       const int row = row0 + tid;
       const uint16_t *cl = pd.cols_local + size_t(row) * pd.W;
       double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
@@ -1060,15 +1232,22 @@ int quantile_param(double q, int64_t n, QuantileParam *qp, int64_t *k_lo, int64_
 }
 
 // ---- launchers --------------------------------------------------------------------------------
-template <int EPL>
-static int launch_thr_epl(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
-                          hipStream_t stream) {
-  auto kern = thresholds_kernel<EPL>;
+template <int EPL, bool SELECT>
+static int launch_thr_epl_sel(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
+                              hipStream_t stream) {
+  auto kern = thresholds_kernel<EPL, SELECT>;
   HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)n_cells), dim3(kThrThreads), lds, stream, pd, x, n_cells, out);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
+}
+
+template <int EPL>
+static int launch_thr_epl(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
+                          hipStream_t stream) {
+  return pd.select ? launch_thr_epl_sel<EPL, true>(pd, lds, x, n_cells, out, stream)
+                   : launch_thr_epl_sel<EPL, false>(pd, lds, x, n_cells, out, stream);
 }
 
 template <int LPC, bool VEC, int NG>
@@ -1157,6 +1336,10 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
     }
     pd.clk = plan->clk.as<unsigned long long>();
   }
+  // rank selection pays once the merge is deep (a lane per (row, rank) instead of a lane per row);
+  // HDP_THR_SELECT=0/1 forces the choice for tests
+  pd.select = (plan->W <= 16) && (plan->steps_top + plan->steps_bot >= 512);
+  if (const char *env = getenv("HDP_THR_SELECT")) pd.select = (plan->W <= 16) && atoi(env) != 0;
   const char *pipe_env = getenv("HDP_THR_PIPE");
   if (plan->pipe && !(pipe_env && atoi(pipe_env) == 0) && !(pd.debug & 8)) {
     switch (plan->lpc) {

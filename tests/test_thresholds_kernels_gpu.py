@@ -3,7 +3,9 @@
 The library picks a kernel from the plan: the pipelined kernel (wave-specialised, register sort with
 8 * LPC keys per column, LPC in {1, 2, 4, 8, 16}; 16-byte gathers when the calendar is regular; merge
 templated on the number of head groups NG in {1, 2, 4}, generic rescan for wider windows) or the
-one-workgroup-per-cell kernel (HDP_THR_PIPE=0, also the path for more than 128 samples per column).
+one-workgroup-per-cell kernel (HDP_THR_PIPE=0, also the path for more than 128 samples per column), which
+finishes a block either with the merge or, when the requested ranks lie deep (HDP_THR_SELECT), with a rank
+selection per (row, requested rank).
 The environment switches are read at launch, so one process can run them all on the same input.
 """
 import zlib
@@ -62,7 +64,7 @@ def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
         want = c_oracle.thresholds(x, win, q)
 
     def run(**env):
-        for k in ("HDP_THR_PIPE", "HDP_THR_VEC"):
+        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -71,7 +73,8 @@ def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
     got = run()
     assert same_f64(got, want)
     assert same_f64(run(HDP_THR_VEC="0"), want)       # pipelined kernel, one dword per (column, sample)
-    assert same_f64(run(HDP_THR_PIPE="0"), want)      # one workgroup per cell
+    assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="0"), want)   # one workgroup per cell, merge
+    assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="1"), want)   # same, rank selection per (row, rank)
 
 
 def test_pipelined_kernel_many_cells_vs_single_cell_launches():
