@@ -206,7 +206,7 @@ def main():
             traffic = float(tp[dom]["bytes_per_cell"]) * bc
     except Exception:
         traffic = None
-    dom_name = {"thresholds_kernel": "thresholds_pipe_kernel (sort producers + merge, one launch per band)",
+    dom_name = {"thresholds_kernel": tplan.describe() + ", one launch per band",
                 "metrics_kernel": "exceed_kernel + metrics_kernel_cells16 (batches of series, two overlapping launches per batch, timed together)"}[dom]
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kern[dom]["frac_hbm"], "traffic": traffic,

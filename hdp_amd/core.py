@@ -219,6 +219,10 @@ class ThresholdPlan:
         """Device pointers; out is [n_cells][P][n_doy] float64 (percentile-major, what MetricsPlan.run reads)."""
         _lib.check(self.lib.hdp_thresholds_f32_dev(self.handle, x_ptr, int(n_cells), out_ptr, stream))
 
+    def describe(self):
+        """The kernel a launch runs now (plan choice under the HDP_THR_* switches)."""
+        return self.lib.hdp_threshold_plan_describe(self.handle).decode()
+
     def __del__(self):
         try:
             if self.handle:

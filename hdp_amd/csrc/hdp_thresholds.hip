@@ -1289,6 +1289,44 @@ static int launch_thr_pipe_ng(const ThrDev &pd, size_t lds, const float *x, int6
   }
 }
 
+// Which kernel a launch of this plan runs: the plan's choice, overridden by the environment switches
+// (read at every launch so one process can compare the variants on the same input).
+struct ThrVariant {
+  bool pipe, vec, select;
+};
+static ThrVariant thr_variant(const hdp_threshold_plan *plan, int debug) {
+  ThrVariant v;
+  const char *pipe_env = getenv("HDP_THR_PIPE");
+  v.pipe = plan->pipe && !(pipe_env && atoi(pipe_env) == 0) && !(debug & 8);
+  const char *vec_env = getenv("HDP_THR_VEC");
+  v.vec = v.pipe && plan->lpc == 16 && plan->vec && !(vec_env && atoi(vec_env) == 0);
+  // rank selection pays once the merge is deep (a lane per (row, rank) instead of a lane per row);
+  // HDP_THR_SELECT=0/1 forces the choice for tests
+  v.select = !v.pipe && (plan->W <= 16) && (plan->steps_top + plan->steps_bot >= 512);
+  if (const char *env = getenv("HDP_THR_SELECT")) v.select = !v.pipe && (plan->W <= 16) && atoi(env) != 0;
+  return v;
+}
+
+extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *plan) {
+  static thread_local char buf[256];
+  if (!plan) return "";
+  const int debug = getenv("HDP_THR_DEBUG") ? atoi(getenv("HDP_THR_DEBUG")) : 0;
+  const ThrVariant v = thr_variant(plan, debug);
+  if (v.pipe)
+    snprintf(buf, sizeof buf,
+             "thresholds_pipe_kernel<LPC=%d,%s,NG=%d> (register sort producers + %d merging waves; %d rows x %d blocks, "
+             "%zu B LDS)",
+             plan->lpc, v.vec ? "16-byte gathers" : "dword gathers", (plan->Wp >> 2) <= 4 ? (plan->Wp >> 2) : 0,
+             plan->n_merge, plan->rows_per_block, plan->n_blocks, plan->lds_bytes);
+  else
+    snprintf(buf, sizeof buf,
+             "thresholds_kernel<EPL=%d,%s> (one workgroup per cell: LDS columns, wave sort, %s; %d rows x %d blocks, "
+             "%zu B LDS)",
+             plan->epl, v.select ? "select" : "merge", v.select ? "rank selection per (row, rank)" : "W-way merge per row",
+             plan->rows_per_block, plan->n_blocks, plan->lds_bytes);
+  return buf;
+}
+
 int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_t n_cells,
                       double *out_dev, hipStream_t stream) {
   if (n_cells == 0) return HDP_OK;
@@ -1336,23 +1374,17 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
     }
     pd.clk = plan->clk.as<unsigned long long>();
   }
-  // rank selection pays once the merge is deep (a lane per (row, rank) instead of a lane per row);
-  // HDP_THR_SELECT=0/1 forces the choice for tests
-  pd.select = (plan->W <= 16) && (plan->steps_top + plan->steps_bot >= 512);
-  if (const char *env = getenv("HDP_THR_SELECT")) pd.select = (plan->W <= 16) && atoi(env) != 0;
-  const char *pipe_env = getenv("HDP_THR_PIPE");
-  if (plan->pipe && !(pipe_env && atoi(pipe_env) == 0) && !(pd.debug & 8)) {
+  const ThrVariant var = thr_variant(plan, pd.debug);
+  pd.select = var.select;
+  if (var.pipe) {
     switch (plan->lpc) {
       case 1: return launch_thr_pipe_ng<1, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       case 2: return launch_thr_pipe_ng<2, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       case 4: return launch_thr_pipe_ng<4, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       case 8: return launch_thr_pipe_ng<8, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       default: {
-        const char *vec_env = getenv("HDP_THR_VEC");
-        if (pd.debug & 4096)
-          fprintf(stderr, "[hdp thresholds] pipe: vec plan=%d env=%s n_merge=%d rows=%d lds=%zu\n", (int)plan->vec,
-                  vec_env ? vec_env : "-", plan->n_merge, plan->rows_per_block, plan->lds_bytes);
-        if (plan->vec && !(vec_env && atoi(vec_env) == 0))
+        if (pd.debug & 4096) fprintf(stderr, "[hdp thresholds] %s\n", hdp_threshold_plan_describe(plan));
+        if (var.vec)
           return launch_thr_pipe_ng<16, true>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
         return launch_thr_pipe_ng<16, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       }

@@ -91,6 +91,9 @@ int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_doy, int64_t 
                               const double *q, int64_t P, int64_t T,
                               hdp_threshold_plan **plan_out);
 int hdp_threshold_plan_destroy(hdp_threshold_plan *plan);
+/* Human-readable name and shape of the kernel a launch of this plan runs now (the plan's choice
+ * under the HDP_THR_* environment switches); thread-local storage, valid until the next call. */
+const char *hdp_threshold_plan_describe(const hdp_threshold_plan *plan);
 
 /* x_dev [n_cells][T] float32 time-contiguous -> out_dev [n_cells][P][n_doy] float64.
  * PERCENTILE-MAJOR: the device layout, what hdp_metrics_f32_dev consumes (day-of-year rows are the
