@@ -41,6 +41,10 @@ CASES = [
     ("S16-lpc2-full", "0001-01-01", "0016-12-31", 2, [0.0, 0.5, 1.0], 5, False),
     ("S64-lpc8-full", "0001-01-01", "0064-12-31", 7, [0.9, 0.99], 3, False),
     ("S128-lpc16-full", "0001-01-01", "0128-12-31", 7, [0.05, 0.95], 2, True),
+    # more than 128 samples per column: LDS columns, lane-major wave sort (4, 8, 16 keys per lane), merge or selection
+    ("S150-epl4-ragged", "0001-01-01", "0150-06-30", 7, [0.0, 0.02, 0.5, 0.93, 1.0], 3, True),
+    ("S260-epl8", "0001-01-01", "0260-12-31", 3, [0.2, 0.8, 0.99], 3, True),
+    ("S600-epl16-w5", "0001-01-01", "0600-12-31", 2, [0.001, 0.35, 0.65, 0.999], 2, False),
 ]
 
 
