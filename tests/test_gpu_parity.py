@@ -453,6 +453,60 @@ def test_c2_full_size_cross_kernel_properties(monkeypatch):
     assert np.array_equal(split[:, :, sample].astype(np.int64), want)
 
 
+def test_c3_shape_slice_cross_kernel_properties(monkeypatch):
+    """BASELINE config 3's series shape (36500 d = 100 noleap years, S = 100 samples per day of year, 151-step
+    merges, 100 seasons) on a 2048-cell slice spanning both hemispheres -- the kernel variants the headline
+    bench runs (16-byte-gather pipelined thresholds kernel, packed series-per-lane state machine):
+      * pipelined / one-workgroup-per-cell merge / rank-selection thresholds kernels agree bit for bit;
+      * packed 16-bit, 32-bit and (percentile, definition)-per-lane metrics kernels agree bit for bit;
+      * monotone thresholds, HWF >= HWD >= HWA >= 0, HWN <= HWF, HWA == HWF // HWN;
+      * a sample of cells matches the C oracle exactly."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(33)
+    dates = orc.noleap_date_range("1901-01-01", "2000-12-31")
+    T, n = dates.size, 2048
+    lat = np.linspace(-80, 80, n)
+    t = np.arange(T, dtype=np.float32)
+    season = (20 + 2 * np.sin(2 * np.pi * (t + 90) / 365)).astype(np.float32)
+    base = season[None, :] - (10 * np.abs(lat) / 90).astype(np.float32)[:, None] \
+        + rng.random(size=(n, T), dtype=np.float32) * np.float32(0.35)
+    meas = base + (t / np.float32(36500.0))[None, :]
+    meas[:, ::3] += np.float32(0.05)
+    q = np.arange(0.9, 1, 0.01)
+    defs = [[3, 0, 0], [3, 1, 1], [4, 0, 0], [4, 1, 1], [5, 0, 0], [5, 1, 1]]
+    ti, cols = cal.window_columns(dates, 7)
+    assert ti.shape == (365, 100)
+    thr = core.compute_percentiles(base, ti, cols, q)
+    assert thr.shape == (n, 365, 10) and not np.isnan(thr).any() and np.all(np.diff(thr, axis=2) >= 0)
+    monkeypatch.setenv("HDP_THR_PIPE", "0")
+    assert same_f64(thr, core.compute_percentiles(base, ti, cols, q))
+    monkeypatch.setenv("HDP_THR_SELECT", "1")
+    assert same_f64(thr[:256], core.compute_percentiles(base[:256], ti, cols, q))
+    monkeypatch.delenv("HDP_THR_SELECT")
+    monkeypatch.delenv("HDP_THR_PIPE")
+    sample = rng.choice(n, size=16, replace=False)
+    win = cal.expand_window_table(ti, cols)
+    assert same_f64(thr[sample], c_oracle.thresholds(base[sample], win, q))
+
+    doy_map = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    is_south = (lat < 0).astype(np.uint8)
+    packed = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
+    monkeypatch.setenv("HDP_METRICS_PACKED", "0")
+    unpacked = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
+    monkeypatch.delenv("HDP_METRICS_PACKED")
+    monkeypatch.setenv("HDP_METRICS_CELLS", "0")
+    pairs = core.compute_heatwave_metrics(meas, thr, doy_map, defs, north, south, is_south)
+    monkeypatch.delenv("HDP_METRICS_CELLS")
+    assert np.array_equal(packed, unpacked) and np.array_equal(packed, pairs)
+    hwf, hwn, hwd, hwa = (packed[:, :, :, i, :].astype(np.int64) for i in range(4))
+    assert packed.shape[-1] == 100 and hwf.min() >= 0 and np.all(hwf >= hwd) and np.all(hwd >= hwa) and np.all(hwn <= hwf)
+    assert np.array_equal(hwa, np.where(hwn > 0, hwf // np.maximum(hwn, 1), 0))
+    assert np.all(hwf[hwn == 0] == 0) and hwf.max() <= 153 and hwf.sum() > 0
+    want = c_oracle.metrics(meas[sample], thr[sample], doy_map, defs, north, south, is_south[sample])
+    assert np.array_equal(packed[:, :, sample].astype(np.int64), want)
+
+
 def test_time_major_inputs_through_device_transpose():
     """CMIP order [time, cells] (stride_cell == 1): strided 2-D upload + device transpose must give
     exactly what the time-contiguous copy gives, for both passes; odd sizes exercise tile edges."""
