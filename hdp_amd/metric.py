@@ -4,6 +4,7 @@ heatwave detection runs in the fused HIP kernel instead of Numba + apply_ufunc l
 
   compute_individual_metrics <- hdp/metric.py:372-506
   compute_group_metrics      <- hdp/metric.py:509-523
+  compute_metrics_io         <- hdp/metric.py:526-590 (adds latitude-band streaming)
   index_heatwaves, heatwave_frequency/number/duration/average, indicate_hot_days
                              <- hdp/metric.py:11-172,280-301 (GPU mirrors, same signatures)
   get_range_indices, build_doy_map, compute_hemisphere_ranges
@@ -11,9 +12,12 @@ heatwave detection runs in the fused HIP kernel instead of Numba + apply_ufunc l
 """
 from __future__ import annotations
 
+from pathlib import Path
+
 import numpy as np
 
 from . import core
+from . import io as hio
 from ._xr import backend, jan1_stamps
 from .calendar import build_doy_map, get_range_indices, hemisphere_season_tables  # noqa: F401
 from .core import (heatwave_average, heatwave_duration, heatwave_frequency, heatwave_number,  # noqa: F401
@@ -150,3 +154,42 @@ def compute_group_metrics(measures, thresholds, hw_definitions, include_threshol
     aggr.attrs["variable_naming_desc"] = "(heat measure).(threshold used).(heatwave metric)"
     aggr.attrs["variable_naming_delimeter"] = "."
     return aggr
+
+
+def compute_metrics_io(output_path: str, measure_path: str, measure_var: str, threshold_path: str, hw_definitions: list,
+                       include_threshold: bool = False, override_threshold_var: str = None, overwrite: bool = False,
+                       lat_band: int = None) -> None:
+    """Heatwave metrics from a measure file / store and a threshold file / store, written to
+    ``output_path`` (``.zarr`` or ``.nc``) (metric.py:526-590: same arguments, checks and exceptions).
+
+    The threshold variable is ``override_threshold_var`` when given (variables are then checked like
+    ``compute_individual_metrics`` does); otherwise the documented default ``threshold_{measure_var}``
+    or, when the dataset does not hold it, the name ``compute_threshold`` writes, ``{measure_var}_threshold``
+    -- without the attribute checks, as in the reference (:558-560).  ``overwrite`` is what the
+    reference's body refers to without declaring it; ``lat_band`` (not in the reference) streams the
+    grid ``lat_band`` latitude rows at a time."""
+    output_path = hio.prepare_output(output_path, overwrite)
+    measure_ds = hio.open_dataset(Path(measure_path))
+    threshold_ds = hio.open_dataset(Path(threshold_path))
+    check_variables = override_threshold_var is not None
+    if override_threshold_var is not None:
+        threshold_var = override_threshold_var
+    else:
+        threshold_var = f"threshold_{measure_var}"
+        if threshold_var not in threshold_ds and f"{measure_var}_threshold" in threshold_ds:
+            threshold_var = f"{measure_var}_threshold"
+    measure_data = measure_ds[measure_var]
+    threshold_data = threshold_ds[threshold_var]
+    if lat_band and "lat" in measure_data.dims:
+        n_lat = measure_data.shape[list(measure_data.dims).index("lat")]
+        parts = []
+        for a, b in hio.lat_slices(n_lat, lat_band):
+            parts.append(compute_individual_metrics(measure_data.isel(lat=slice(a, b)),
+                                                    threshold_data.isel(lat=slice(a, b)), hw_definitions,
+                                                    include_threshold=include_threshold,
+                                                    check_variables=check_variables))
+        metric_ds = hio.concat_lat(parts)
+    else:
+        metric_ds = compute_individual_metrics(measure_data, threshold_data, hw_definitions,
+                                               include_threshold=include_threshold, check_variables=check_variables)
+    hio.write_dataset(metric_ds, output_path)

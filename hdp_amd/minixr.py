@@ -6,7 +6,9 @@ have no xarray (and no network to install it), so the same code paths are exerci
 there with these stand-ins, which implement exactly the subset of the xarray API that
 the adapters and the reference's own workflow test touch: ``dims``, ``shape``,
 ``dtype``, ``values``, ``coords``, ``attrs``, ``name``, ``rename``, ``mean``,
-``compute``, item/attribute access on a Dataset, ``data_vars`` and ``merge``.
+``compute``, item/attribute access on a Dataset, ``data_vars``, ``merge``, and -- for the latitude-band
+streaming of the ``*_io`` wrappers -- ``isel`` with slices and ``concat`` along an existing dimension.
+It does no file I/O (``open_dataset`` / ``to_netcdf`` / ``to_zarr`` need the real xarray).
 """
 from __future__ import annotations
 
@@ -53,6 +55,18 @@ class DataArray:
 
     def compute(self):
         return self
+
+    def isel(self, **indexers):
+        """Slices only (what the band streaming needs); coordinates of the sliced dims follow."""
+        index = [slice(None)] * self.values.ndim
+        coords = self._coord_dict()
+        for dim, sl in indexers.items():
+            if not isinstance(sl, slice):
+                raise TypeError("minixr.isel takes slices")
+            index[self.dims.index(dim)] = sl
+            if dim in coords:
+                coords[dim] = coords[dim][sl]
+        return DataArray(self.values[tuple(index)], self.dims, coords, self.name, self.attrs)
 
     def astype(self, dtype):
         return DataArray(self.values.astype(dtype), self.dims, self._coord_dict(), self.name, self.attrs)
@@ -163,4 +177,26 @@ def merge(datasets):
             out[k] = v
         for ak, av in ds.attrs.items():   # combine_attrs="override"-like: first one wins
             out.attrs.setdefault(ak, av)
+    return out
+
+
+def concat(datasets, dim):
+    """Datasets along an existing dimension: variables (and the coordinate) that carry ``dim`` are
+    concatenated in order, everything else and all attrs come from the first Dataset."""
+    first = datasets[0]
+    coords = {k: v.values for k, v in first.coords.items()}
+    if dim in coords:
+        coords[dim] = np.concatenate([np.asarray(ds.coords[dim].values) for ds in datasets])
+    out = Dataset(coords=coords, attrs=first.attrs)
+    for ck, cv in first.coords.items():
+        out.coords[ck].attrs = dict(cv.attrs)
+    for name, da in first.data_vars.items():
+        if dim in da.dims:
+            axis = da.dims.index(dim)
+            values = np.concatenate([ds.data_vars[name].values for ds in datasets], axis=axis)
+            c = da._coord_dict()
+            c[dim] = coords[dim]
+            out[name] = DataArray(values, da.dims, c, name, da.attrs)
+        else:
+            out[name] = da
     return out

@@ -144,3 +144,34 @@ def test_full_data_workflow_with_relative_humidity():
     x = baseline_measures["temp_hi"].values.reshape(-1, base.shape[-1])
     want_thr = orc.compute_thresholds_cells(x, orc.datetimes_to_windows(bdates, 7), percentiles)
     assert np.array_equal(thresholds["temp_hi_threshold"].values.reshape(want_thr.shape), want_thr)
+
+
+def test_io_wrappers_band_streaming_on_the_device(tmp_path, monkeypatch):
+    """compute_threshold_io / compute_metrics_io through the real kernels: streaming the grid in bands of
+    latitude rows gives the same Datasets as one pass (files are an in-memory dict: no xarray I/O here)."""
+    from hdp_amd import _xr, minixr
+    if _xr.backend() is not minixr:
+        pytest.skip("in-memory store is built on the stand-in container")
+    files = {}
+    monkeypatch.setattr(minixr, "open_dataset", lambda path: files[str(path)], raising=False)
+    monkeypatch.setattr(minixr.Dataset, "to_netcdf", lambda self, path: files.__setitem__(str(path), self), raising=False)
+    base, lon, lat, bdates = utils.generate_control_array(start_date="1700-01-01", end_date="1709-12-31",
+                                                          grid_shape=(3, 7), add_noise=True, seed=5)
+    warm, _, _, mdates = utils.generate_warming_array(start_date="2000-01-01", end_date="2009-12-31",
+                                                      grid_shape=(3, 7), add_noise=True)
+    files[str(tmp_path / "base.nc")] = measure_dataset(base, lon, lat, bdates)
+    files[str(tmp_path / "meas.nc")] = measure_dataset(warm, lon, lat, mdates)
+    q = np.arange(0.9, 1, 0.02)
+    defs = [[3, 0, 0], [3, 1, 1], [5, 2, 2]]
+    hdp_amd.threshold.compute_threshold_io(tmp_path / "base.nc", "temp", tmp_path / "thr.nc", q)
+    hdp_amd.threshold.compute_threshold_io(tmp_path / "base.nc", "temp", tmp_path / "thr_b.nc", q, lat_band=2)
+    whole, banded = files[str(tmp_path / "thr.nc")], files[str(tmp_path / "thr_b.nc")]
+    assert np.array_equal(whole["temp_threshold"].values, banded["temp_threshold"].values)
+    assert np.array_equal(whole["lat"].values, banded["lat"].values)
+    hdp_amd.metric.compute_metrics_io(tmp_path / "hw.nc", tmp_path / "meas.nc", "temp", tmp_path / "thr.nc", defs)
+    hdp_amd.metric.compute_metrics_io(tmp_path / "hw_b.nc", tmp_path / "meas.nc", "temp", tmp_path / "thr_b.nc", defs,
+                                      override_threshold_var="temp_threshold", lat_band=3)
+    for name in ("HWF", "HWN", "HWD", "HWA"):
+        a, b = files[str(tmp_path / "hw.nc")][name], files[str(tmp_path / "hw_b.nc")][name]
+        assert tuple(a.dims) == tuple(b.dims) and np.array_equal(a.values, b.values) and a.values.sum() >= 0
+    assert files[str(tmp_path / "hw.nc")]["HWF"].values.sum() > 0
