@@ -4,20 +4,23 @@
 // for every grid cell and every day-of-year row, the quantiles of the B = W*S samples
 // whose time indices the window table lists (threshold.py:12-49).
 //
-// Algorithm (one workgroup per cell, looping over blocks of day-of-year rows):
-//   1. load   the samples of the block's day-of-year COLUMNS (S samples each: one per
-//             year x member) from HBM into LDS through a host-built (t -> LDS slot) list
-//             sorted by t, so the HBM side is read in contiguous runs;
-//   2. sort   every column once, descending, in registers (bitonic network over
-//             64*EPL elements, one wave per column) -- valid for every window that uses
-//             the column, and adjacent windows share 14 of their 15 columns;
-//   3. merge  one lane per day-of-year row: W-way merge of the window's sorted columns
-//             from the top (and/or from the bottom, whichever end the requested ranks
-//             are nearer to), recording the order statistics numba's quantile needs;
-//   4. interpolate in float64 with numba's operation order, lower*(1-m) + upper*m,
-//             no FMA contraction (this file is compiled with -ffp-contract=off).
+// Common idea: sort every day-of-year COLUMN (S samples: one per year x member) once,
+// descending -- valid for every window that uses the column, and adjacent windows share
+// 14 of their 15 columns -- then take the requested order statistics of each row's window
+// out of its W sorted columns and interpolate in float64 with numba's operation order,
+// lower*(1-m) + upper*m, no FMA contraction (this file is compiled with -ffp-contract=off).
 //
-// This path is LDS/VALU (sort) bound, not MFMA work; its roofline is HBM bandwidth:
+// Three kernels, same results bit for bit (tests/test_thresholds_kernels_gpu.py):
+//   thresholds_pipe_kernel<LPC, VEC, NG>   S <= 128 (the headline config: S = 100).  Persistent
+//             workgroups, waves specialised: producers gather a block's columns straight from
+//             HBM into registers and sort them there (DPP rows, v_med3), merging waves run a
+//             W-way merge per row (one lane per row) out of the LDS image of the previous block.
+//   thresholds_kernel<EPL, false>          any S <= 2048: one workgroup per cell, load -> LDS,
+//             wave sort (lane-major bitonic network), W-way merge per row.
+//   thresholds_kernel<EPL, true>           the same with a rank SELECTION per (row, requested
+//             rank) instead of the merge, for deep ranks (10-member ensemble: S = 1000).
+//
+// This path is VALU/LDS (sort + merge) work, not MFMA work; its roofline is HBM bandwidth:
 // algorithmic bytes per cell = 4*T (read) + 8*n_doy*P (write).
 #include "hdp_internal.hpp"
 
@@ -69,46 +72,11 @@ __device__ __forceinline__ float key_f32(int k) { return __int_as_float(k ^ ((k 
 constexpr int kKeyMax = 0x7f900000;
 constexpr int kKeyMin = (int)0x80400000;
 
-// ---- column sort: 64*EPL elements held as v[r] = element (r*64 + lane), descending ----
-// One compare-exchange stage: partner = e ^ mask, the element whose `top` bit is clear
-// keeps the larger value.  After full unrolling mask/top are compile-time constants.
-template <int EPL>
-__device__ __forceinline__ void cmp_stage(float (&v)[EPL], int lane, int mask, int top) {
-  const int ml = mask & 63;
-  const int mr = mask >> 6;
-  float nv[EPL];
-#pragma unroll
-  for (int r = 0; r < EPL; ++r) {
-    const float self = v[r];
-    float other = v[r ^ mr];
-    if (ml) other = __shfl_xor(other, ml, 64);
-    const bool keep_max = (top >= 64) ? ((r & (top >> 6)) == 0) : ((lane & top) == 0);
-    const bool take = keep_max ? (other > self) : (other < self);
-    nv[r] = take ? other : self;
-  }
-#pragma unroll
-  for (int r = 0; r < EPL; ++r) v[r] = nv[r];
-}
-
-template <int EPL>
-__device__ __forceinline__ void bitonic_desc(float (&v)[EPL], int lane) {
-  constexpr int N2 = 64 * EPL;
-  // the first step of each merge mirrors (partner = e ^ (k-1)), the rest are
-  // half-cleaners (partner = e ^ j); every comparator keeps the larger value at the
-  // smaller index, so -inf padding at the tail never moves.
-#pragma unroll
-  for (int k = 2; k <= N2; k <<= 1) {
-    cmp_stage<EPL>(v, lane, k - 1, k >> 1);
-#pragma unroll
-    for (int j = k >> 2; j >= 1; j >>= 1) cmp_stage<EPL>(v, lane, j, j);
-  }
-}
-
 // ---- 16-lane-row sorter for S <= 128: four columns per wave, no LDS traffic ------------------
 // Each 16-lane DPP row owns one column; lane l of the row holds elements e = 8*l + i (i = 0..7).
 // Distances 1, 2, 4 are register-to-register, distances 8..64 are lane xor 1, 2, 4 (+ the mirrored
 // first step of each merge), all of which DPP serves inside a row: quad_perm, row_half_mirror,
-// row_mirror and a row_shl/row_shr pair.  Same comparator network as bitonic_desc.
+// row_mirror and a row_shl/row_shr pair.  Same comparator network as bitonic_desc_lm below.
 template <int CTRL, int BANK_MASK = 0xf>
 __device__ __forceinline__ float dpp_mov(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf,
@@ -154,7 +122,8 @@ __device__ __forceinline__ void ce_reg(float &a, float &b) {  // larger value to
 // Element e = lane * EPL + r, so the log2(EPL) short distances of every merge are register-to-register
 // and only 21 of the 55 stages of a 1024-key sort cross lanes (45 with e = r * 64 + lane); of those,
 // lane xor 1, 2, 3, 4, 7, 8, 15 are DPP moves and only xor 16, 31, 63 go through ds_bpermute.
-// Same comparator network as bitonic_desc, so the sorted column is identical.
+// The network (mirrored first step of every merge, then half-cleaners) keeps the larger key at the smaller index,
+// so -inf padding at the tail never moves.
 template <int ML>
 __device__ __forceinline__ float lane_xor(float v) {
   if constexpr (ML == 1 || ML == 2 || ML == 3 || ML == 4 || ML == 7 || ML == 15) return row_xor<ML>(v);
