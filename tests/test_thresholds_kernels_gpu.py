@@ -95,3 +95,45 @@ def test_pipelined_kernel_many_cells_vs_single_cell_launches():
     win = cal.expand_window_table(ti, cols)
     sel = rng.choice(x.shape[0], 24, replace=False)
     assert same_f64(got[sel], c_oracle.thresholds(x[sel], win, q))
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_calendars_windows_and_quantiles(seed, monkeypatch):
+    """Seeded random configurations -- years of record (1..260 samples per day of year), a ragged last year,
+    window radius 0..12 (up to 25 columns: the generic merge; selection only up to 16), 1..6 quantiles anywhere
+    in [0, 1], ties and special values -- every kernel variant against the C oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    years = int(rng.choice([1, 2, 3, 7, 11, 19, 33, 64, 65, 100, 129, 180, 260]))
+    end_month, end_day = (12, 31) if rng.random() < 0.5 else (int(rng.integers(1, 12)), int(rng.integers(1, 28)))
+    dates = orc.noleap_date_range("0001-01-01", f"{years:04d}-{end_month:02d}-{end_day:02d}")
+    T = dates.size
+    if T < 365:
+        dates = orc.noleap_date_range("0001-01-01", "0001-12-31")
+        T = dates.size
+    radius = int(rng.integers(0, 13))
+    n_q = int(rng.integers(1, 7))
+    q = np.sort(rng.random(n_q))
+    if rng.random() < 0.3:
+        q[0] = 0.0
+    if rng.random() < 0.3:
+        q[-1] = 1.0
+    n_cells = int(rng.integers(1, 10))
+    x = rng.normal(0, 5, size=(n_cells, T)).astype(np.float32)
+    if rng.random() < 0.5:
+        x = np.round(x)                               # heavy ties
+    if rng.random() < 0.4:
+        x[0, rng.integers(0, T, 4)] = np.inf
+        x[0, rng.integers(0, T, 4)] = -np.inf
+    if rng.random() < 0.3:
+        x[-1, rng.integers(0, T)] = np.nan
+    ti, cols = cal.window_columns(dates, radius)
+    win = cal.expand_window_table(ti, cols)
+    with np.errstate(invalid="ignore"):
+        want = c_oracle.thresholds(x, win, q)
+    for env in ({}, {"HDP_THR_VEC": "0"}, {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "0"},
+                {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "1"}):
+        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert same_f64(core.compute_percentiles(x, ti, cols, q), want), (env, years, radius, q)
