@@ -232,6 +232,27 @@ def main():
         pre_step = {"kernel": "heat_index_kernel<celsius>", "elements": n_el, "ms": hms.value / reps,
                     "GBps": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
 
+    # ---- post-step: latitude-weighted spatial mean of the resident int16 metrics, one row per
+    # (metric, percentile, definition, season) over this band's series; reported beside `value`
+    post_step = None
+    if rank == 0:
+        n_rows, n_ser = 4 * P * D * int(Yp), M * bc
+        w_dev = torch.from_numpy(np.cos(np.deg2rad(np.tile(lat_cells[:bc], M).astype(np.float64)))).to(dev)
+        mean_dev = torch.empty(n_rows, dtype=torch.float64, device=dev)
+        e0, e1 = lib.hdp_event_create(), lib.hdp_event_create()
+        _lib.check(lib.hdp_weighted_mean_i16_dev(out.data_ptr(), n_rows, n_ser, w_dev.data_ptr(), mean_dev.data_ptr(), stream))
+        lib.hdp_event_record(e0, stream)
+        reps = 3
+        for _ in range(reps):
+            _lib.check(lib.hdp_weighted_mean_i16_dev(out.data_ptr(), n_rows, n_ser, w_dev.data_ptr(), mean_dev.data_ptr(), stream))
+        lib.hdp_event_record(e1, stream)
+        wms = ctypes.c_float()
+        _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(wms)))
+        gbps = (2.0 * n_rows * n_ser + 8.0 * n_ser + 8.0 * n_rows) * reps / (wms.value * 1e-3) / 1e9
+        post_step = {"kernel": "weighted_rows_mean_i16x8_kernel", "rows": n_rows, "series": n_ser,
+                     "ms": wms.value / reps, "GBps": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
+        del w_dev, mean_dev
+
     # ---- RCCL all-gather of the metrics (reassembly step of north_star), reported separately ------------
     allgather = None
     if world > 1:
@@ -307,7 +328,7 @@ def main():
                        "cells_per_gpu": int(cells_rank_eff), "members": M, "T": T, "percentiles": P, "definitions": D,
                        "seasons": int(Y), "resident_bands_per_step": n_bands, "cells_per_band": int(bc),
                        "sharding": "independent grid cells per rank, no data-path collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "pre_step": pre_step, "allgather": allgather,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "pre_step": pre_step, "post_step": post_step, "allgather": allgather,
             "parity_sample": parity, "device": _lib.device_info(),
         }
         print(json.dumps(line))

@@ -63,6 +63,8 @@ SIGNATURES = {
     "hdp_heat_index_f32": (C.c_int, [vp, vp, i64, vp]),
     "hdp_heat_index_f32_dev": (C.c_int, [vp, vp, i64, vp, vp]),
     "hdp_heat_index_celsius_f32_dev": (C.c_int, [vp, vp, i64, vp, vp]),
+    "hdp_weighted_mean_i16_dev": (C.c_int, [vp, i64, i64, vp, vp, vp]),
+    "hdp_weighted_mean_f64": (C.c_int, [vp, i64, i64, vp, vp]),
     "hdp_generate_series_dev": (C.c_int, [vp, i64, i64, i64, vp, C.c_uint64, f32, f32, vp]),
 }
 

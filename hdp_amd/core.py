@@ -164,6 +164,23 @@ def heat_index(temp, rel_humid):
     return out
 
 
+def weighted_row_mean(values, weights):
+    """values [n_rows, n] (any real dtype; NaNs are skipped), weights [n] -> float64 [n_rows]:
+    sum_c w[c] v[r][c] / sum_c w[c] over the valid values of row r -- the arithmetic of
+    xarray's ``da.weighted(w).mean(...)`` as the reference's compute_weighted_spatial_mean uses it
+    (hdp/graphics/figure.py:14-15)."""
+    lib = _lib.ensure_device()
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    if v.ndim != 2:
+        raise ValueError("values must be [n_rows, n]")
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    if w.shape != (v.shape[1],):
+        raise ValueError("weights must be [n]")
+    out = np.empty(v.shape[0], dtype=np.float64)
+    _lib.check(lib.hdp_weighted_mean_f64(_ptr(v), v.shape[0], v.shape[1], _ptr(w), _ptr(out)))
+    return out
+
+
 # ---- device-resident interface (bench.py, sharded runs) ----------------------------------
 
 class DeviceArray:

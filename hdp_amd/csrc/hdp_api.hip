@@ -550,6 +550,35 @@ int hdp_heat_index_f32(const float *temp_f, const float *rel_humid, int64_t n, f
   return HDP_OK;
 }
 
+int hdp_weighted_mean_i16_dev(const int16_t *v_dev, int64_t n_rows, int64_t n, const double *w_dev, double *out_dev,
+                              void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n_rows >= 0 && n > 0, HDP_EINVAL, "bad sizes");
+  HDP_REQUIRE(n_rows == 0 || (v_dev && w_dev && out_dev), HDP_EINVAL, "NULL buffer");
+  return launch_weighted_row_mean_i16(v_dev, n_rows, n, w_dev, out_dev, pick(stream));
+}
+
+int hdp_weighted_mean_f64(const double *v, int64_t n_rows, int64_t n, const double *w, double *out) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(n_rows >= 0 && n > 0, HDP_EINVAL, "bad sizes");
+  HDP_REQUIRE(n_rows == 0 || (v && w && out), HDP_EINVAL, "NULL buffer");
+  if (n_rows == 0) return HDP_OK;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t(1) << 27) / n);  // ~1 GiB of rows per pass
+  DevBuf dv, dw, dout;
+  HDP_HIP_TRY(dw.upload(w, size_t(n) * 8));
+  HDP_HIP_TRY(dv.alloc(size_t(std::min(chunk, n_rows)) * n * 8));
+  HDP_HIP_TRY(dout.alloc(size_t(std::min(chunk, n_rows)) * 8));
+  for (int64_t r0 = 0; r0 < n_rows; r0 += chunk) {
+    const int64_t m = std::min(chunk, n_rows - r0);
+    HDP_HIP_TRY(hipMemcpyAsync(dv.p, v + r0 * n, size_t(m) * n * 8, hipMemcpyHostToDevice, g_stream));
+    int rc = launch_weighted_row_mean_f64(dv.as<double>(), m, n, dw.as<double>(), dout.as<double>(), g_stream);
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipMemcpyAsync(out + r0, dout.p, size_t(m) * 8, hipMemcpyDeviceToHost, g_stream));
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  }
+  return HDP_OK;
+}
+
 int hdp_generate_series_dev(float *x_dev, int64_t n_cells, int64_t T, int64_t cell_offset,
                             const float *lat_dev, uint64_t seed, float noise_scale, float trend_per_day,
                             void *stream) {

@@ -155,6 +155,10 @@ int launch_generate(float *x_dev, int64_t n_cells, int64_t T, int64_t cell_offse
                     uint64_t seed, float noise_scale, float trend_per_day, hipStream_t stream);
 int launch_heat_index(const float *temp_dev, const float *rh_dev, int64_t n, float *out_dev, bool celsius,
                       hipStream_t stream);
+int launch_weighted_row_mean_i16(const int16_t *v_dev, int64_t n_rows, int64_t n, const double *w_dev,
+                                 double *out_dev, hipStream_t stream);
+int launch_weighted_row_mean_f64(const double *v_dev, int64_t n_rows, int64_t n, const double *w_dev,
+                                 double *out_dev, hipStream_t stream);
 int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
                      hipStream_t stream);
 int launch_swap_last2_f64(const double *src_dev, int64_t n, int64_t A, int64_t B, double *dst_dev,

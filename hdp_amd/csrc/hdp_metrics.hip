@@ -1222,6 +1222,122 @@ int launch_heat_index(const float *temp_dev, const float *rh_dev, int64_t n, flo
   return HDP_OK;
 }
 
+// ---- weighted mean of every row: the figure deck's compute_weighted_spatial_mean (hdp/graphics/figure.py:14-15,
+// da.weighted(cos(deg2rad(lat))).mean(dim=["lat", "lon"])) on the series-minor device layout, where one row is one
+// (metric, percentile, definition, season) over all series.  out[r] = sum_c w[c] v[r][c] / sum_c w[c] over the
+// non-NaN values (xarray's weighted mean skips NaNs in the data and in the sum of weights alike); float64
+// accumulation in a fixed order (thread-strided partial sums, wave butterfly, four waves through LDS), so the
+// result is reproducible; HBM-bound, the row is read once.
+template <typename TIn>
+__device__ __forceinline__ bool wm_valid(TIn) { return true; }
+template <>
+__device__ __forceinline__ bool wm_valid<double>(double x) { return x == x; }
+template <>
+__device__ __forceinline__ bool wm_valid<float>(float x) { return x == x; }
+
+// Wave butterfly + four waves through LDS; every thread returns the workgroup's sum (fixed order).
+__device__ __forceinline__ double wm_block_sum(double x, double *part /* [4] */) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+  __syncthreads();  // `part` may still be read from the previous reduction
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void weighted_row_mean_kernel(const TIn *__restrict__ v, int64_t n,
+                                                                const double *__restrict__ w,
+                                                                double *__restrict__ out) {
+  __shared__ double part[4];
+  const TIn *row = v + int64_t(blockIdx.x) * n;
+  double sx = 0.0, sw = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const TIn x = row[i];
+    if (wm_valid<TIn>(x)) {
+      sx += w[i] * double(x);
+      sw += w[i];
+    }
+  }
+  const double tx = wm_block_sum(sx, part);
+  const double tw = wm_block_sum(sw, part);
+  if (threadIdx.x == 0) out[blockIdx.x] = tw != 0.0 ? tx / tw : __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// int16 rows (the metrics' device layout), kWmRows rows per workgroup: the float64 weights -- four times the bytes
+// of the values they multiply -- are fetched once for kWmRows rows, eight values per 16-byte load; no NaNs, so the
+// sum of weights is the same for every row.  Needs n % 8 == 0 and 16-byte aligned rows (host-checked).
+constexpr int kWmRows = 4;
+__global__ __launch_bounds__(256) void weighted_rows_mean_i16x8_kernel(const int16_t *__restrict__ v, int64_t n_rows,
+                                                                       int64_t n, const double *__restrict__ w,
+                                                                       double *__restrict__ out) {
+  __shared__ double part[4];
+  const int64_t r0 = int64_t(blockIdx.x) * kWmRows;
+  const uint4 *rows[kWmRows];
+#pragma unroll
+  for (int r = 0; r < kWmRows; ++r) rows[r] = reinterpret_cast<const uint4 *>(v + min(r0 + r, n_rows - 1) * n);
+  double sx[kWmRows], sw = 0.0;
+#pragma unroll
+  for (int r = 0; r < kWmRows; ++r) sx[r] = 0.0;
+  const double2 *w2 = reinterpret_cast<const double2 *>(w);
+  for (int64_t i = threadIdx.x; i < (n >> 3); i += 256) {
+    double wi[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double2 t = w2[(i << 2) + k];
+      wi[2 * k] = t.x;
+      wi[2 * k + 1] = t.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sw += wi[k];
+#pragma unroll
+    for (int r = 0; r < kWmRows; ++r) {
+      const uint4 q = rows[r][i];
+      const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sx[r] += wi[2 * k] * double(int16_t(u[k] & 0xffffu));
+        sx[r] += wi[2 * k + 1] * double(int16_t(u[k] >> 16));
+      }
+    }
+  }
+  const double tw = wm_block_sum(sw, part);
+#pragma unroll
+  for (int r = 0; r < kWmRows; ++r) {
+    const double tx = wm_block_sum(sx[r], part);
+    if (threadIdx.x == 0 && r0 + r < n_rows)
+      out[r0 + r] = tw != 0.0 ? tx / tw : __longlong_as_double(0x7ff8000000000000LL);
+  }
+}
+
+template <typename TIn>
+static int launch_weighted_row_mean_t(const TIn *v_dev, int64_t n_rows, int64_t n, const double *w_dev,
+                                      double *out_dev, hipStream_t stream) {
+  if (n_rows == 0) return HDP_OK;
+  HDP_REQUIRE(n_rows < (int64_t(1) << 31), HDP_EUNSUP, "too many rows for one launch");
+  hipLaunchKernelGGL(weighted_row_mean_kernel<TIn>, dim3((unsigned)n_rows), dim3(256), 0, stream, v_dev, n, w_dev,
+                     out_dev);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+int launch_weighted_row_mean_i16(const int16_t *v_dev, int64_t n_rows, int64_t n, const double *w_dev,
+                                 double *out_dev, hipStream_t stream) {
+  if (n_rows == 0) return HDP_OK;
+  if ((n & 7) == 0 && ((reinterpret_cast<uintptr_t>(v_dev) | reinterpret_cast<uintptr_t>(w_dev)) & 15) == 0) {
+    const int64_t g = (n_rows + kWmRows - 1) / kWmRows;
+    HDP_REQUIRE(g < (int64_t(1) << 31), HDP_EUNSUP, "too many rows for one launch");
+    hipLaunchKernelGGL(weighted_rows_mean_i16x8_kernel, dim3((unsigned)g), dim3(256), 0, stream, v_dev, n_rows, n,
+                       w_dev, out_dev);
+    HDP_HIP_TRY(hipGetLastError());
+    return HDP_OK;
+  }
+  return launch_weighted_row_mean_t<int16_t>(v_dev, n_rows, n, w_dev, out_dev, stream);
+}
+int launch_weighted_row_mean_f64(const double *v_dev, int64_t n_rows, int64_t n, const double *w_dev,
+                                 double *out_dev, hipStream_t stream) {
+  return launch_weighted_row_mean_t<double>(v_dev, n_rows, n, w_dev, out_dev, stream);
+}
+
 // ---- layout: time-major [T][n] (CMIP order) -> series-major [n][T] ---------------------------
 // 64 x 64 tiles through LDS (pitch 65: conflict-free both ways); reads are coalesced along the
 // cell axis, writes along time.  HBM-bound: 8 bytes of traffic per element.

@@ -195,6 +195,15 @@ int hdp_heat_index_f32_dev(const float *temp_f_dev, const float *rel_humid_dev, 
 int hdp_heat_index_celsius_f32_dev(const float *temp_c_dev, const float *rel_humid_dev, int64_t n,
                                    float *out_c_dev, void *stream);
 
+/* ---- weighted spatial mean: replaces compute_weighted_spatial_mean
+ * (hdp/graphics/figure.py:14-15, da.weighted(cos(deg2rad(lat))).mean(dim=["lat","lon"])) --------
+ * out[r] = sum_c w[c] v[r][c] / sum_c w[c] over the non-NaN v[r][c] (NaN when no weight is left),
+ * float64 accumulation in a fixed order.  The _dev form reads the int16 metrics where
+ * hdp_metrics_f32_dev left them: rows = (metric, percentile, definition, season), n = series. */
+int hdp_weighted_mean_i16_dev(const int16_t *v_dev, int64_t n_rows, int64_t n, const double *w_dev,
+                              double *out_dev, void *stream);
+int hdp_weighted_mean_f64(const double *v, int64_t n_rows, int64_t n, const double *w, double *out);
+
 /* ---- synthetic inputs for bench.py (utils.py:61-78 formula) ---- */
 /* x_dev [n_cells][T]: 20 + 2 sin(2 pi (beta + t)/365) - 10|lat|/90 + noise + trend,
  * beta = 90 (south) / 270 (north), noise = u(seed,cell,t) * noise_scale,

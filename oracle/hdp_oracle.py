@@ -419,3 +419,17 @@ def heat_index_celsius(temp_c, rel_humid) -> np.ndarray:
     tf = (t * np.float32(1.8)) + np.float32(32)
     hi = heat_index(tf, rel_humid)
     return (hi - np.float32(32)) / np.float32(1.8)
+
+
+def weighted_spatial_mean(values, lat, n_lon) -> np.ndarray:
+    """compute_weighted_spatial_mean (hdp/graphics/figure.py:14-15) restated: xarray's
+    ``da.weighted(cos(deg2rad(lat))).mean(dim=["lat", "lon"])`` is sum(w*x)/sum(w) over the non-NaN x
+    (xarray/core/weighted.py: _weighted_sum / _sum_of_weights, both masked by da.notnull()).
+    values [..., n_lat, n_lon] -> [...].  xarray is not installed here: parity with it is unpinned."""
+    v = np.asarray(values, dtype=np.float64)
+    w = np.broadcast_to(np.cos(np.deg2rad(np.asarray(lat, dtype=np.float64)))[:, None], v.shape[-2:])
+    valid = ~np.isnan(v)
+    sx = np.where(valid, v * w, 0.0).sum(axis=(-2, -1))
+    sw = np.where(valid, w, 0.0).sum(axis=(-2, -1))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(sw != 0.0, sx / sw, np.nan)

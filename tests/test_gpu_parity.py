@@ -632,3 +632,41 @@ def test_thresholds_extreme_magnitudes_and_subnormals():
     got = core.compute_percentiles(x, ti, cols, q)
     assert same_f64(got, want)
     assert same_f64(core.compute_percentiles_table(x, cal.expand_window_table(ti, cols), q), want)
+
+
+def test_weighted_spatial_mean_matches_numpy_restatement():
+    """compute_weighted_spatial_mean (figure.py:14-15) on the device: float64 rows with NaNs through the host entry
+    point, int16 metrics in the device layout through the _dev entry point; 1e-12 relative against the NumPy
+    restatement (different but fixed summation order; xarray itself is not importable: parity unpinned)."""
+    import ctypes as C
+    from hdp_amd import _lib, figure, minixr
+    rng = np.random.default_rng(8)
+    n_lat, n_lon = 37, 53
+    lat = np.linspace(-90, 90, n_lat)
+    lon = np.linspace(0, 360, n_lon, endpoint=False)
+    v = rng.integers(0, 150, size=(3, 2, n_lat, n_lon, 5)).astype(np.int64)      # (percentile, definition, lat, lon, time)
+    da = minixr.DataArray(v, dims=["percentile", "definition", "lat", "lon", "time"],
+                          coords={"percentile": [0.9, 0.95, 0.99], "definition": ["a", "b"], "lat": lat, "lon": lon,
+                                  "time": np.arange(5)}, name="HWF")
+    got = figure.compute_weighted_spatial_mean(da)
+    assert tuple(got.dims) == ("percentile", "definition", "time") and got.shape == (3, 2, 5)
+    want = orc.weighted_spatial_mean(np.moveaxis(v, (2, 3), (-2, -1)), lat, n_lon)
+    assert np.allclose(got.values, want, rtol=1e-12, atol=0)
+    f = rng.normal(0, 3, size=(n_lat, n_lon, 4))
+    f[rng.random(f.shape) < 0.2] = np.nan
+    f[:, :, 3] = np.nan                                                       # no valid value: NaN
+    daf = minixr.DataArray(f, dims=["lat", "lon", "time"], coords={"lat": lat, "lon": lon, "time": np.arange(4)})
+    gotf = figure.compute_weighted_spatial_mean(daf).values
+    wantf = orc.weighted_spatial_mean(np.moveaxis(f, 2, 0), lat, n_lon)
+    assert np.isnan(gotf[3]) and np.allclose(gotf[:3], wantf[:3], rtol=1e-12, atol=0)
+    # device layout: int16 rows of n series (vector path: n % 8 == 0; scalar path otherwise)
+    lib = _lib.ensure_device()
+    for n in (4096, 1001):
+        rows = rng.integers(-5, 200, size=(7, n)).astype(np.int16)
+        w = np.cos(np.deg2rad(rng.uniform(-90, 90, n)))
+        dv, dw = core.DeviceArray.from_host(rows), core.DeviceArray.from_host(w)
+        dout = core.DeviceArray((7,), np.float64)
+        _lib.check(lib.hdp_weighted_mean_i16_dev(dv.ptr, 7, n, dw.ptr, dout.ptr, None))
+        _lib.check(lib.hdp_sync(None))
+        out = dout.to_host()
+        assert np.allclose(out, (rows.astype(np.float64) * w).sum(axis=1) / w.sum(), rtol=1e-12, atol=0)

@@ -158,3 +158,23 @@ def test_heat_index_vs_reference_stub_run(golden_dir):
     t, r = g["temp_f"], g["rel_humid"]
     assert ((ref <= 80).sum() > 100 and ((r < 13) & (t >= 80) & (t <= 112)).sum() > 50
             and ((r > 85) & (t >= 80) & (t <= 87)).sum() > 20)
+
+
+def test_weighted_spatial_mean_restatement():
+    """oracle.weighted_spatial_mean (figure.py:14-15 via xarray's weighted mean): a constant field averages to itself
+    whatever the weights, NaNs drop out of both sums, equal weights reduce to the plain mean, and the poles'
+    ~0 weights make them irrelevant."""
+    lat = np.linspace(-90, 90, 7)
+    v = np.full((2, 7, 4), 3.25)
+    assert np.allclose(orc.weighted_spatial_mean(v, lat, 4), 3.25, rtol=1e-15)
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(7, 4))
+    w = np.cos(np.deg2rad(lat))[:, None] * np.ones((1, 4))
+    assert np.isclose(orc.weighted_spatial_mean(x, lat, 4), (x * w).sum() / w.sum(), rtol=1e-14)
+    y = x.copy(); y[2, 1] = np.nan
+    keep = ~np.isnan(y)
+    assert np.isclose(orc.weighted_spatial_mean(y, lat, 4), (x * w)[keep].sum() / w[keep].sum(), rtol=1e-14)
+    assert np.isclose(orc.weighted_spatial_mean(x, np.zeros(7), 4), x.mean(), rtol=1e-14)
+    z = x.copy(); z[0] += 1e6; z[-1] -= 1e6           # rows at the poles carry cos(90 deg) ~ 6e-17
+    assert np.isclose(orc.weighted_spatial_mean(z, lat, 4), orc.weighted_spatial_mean(x, lat, 4), atol=1e-8)
+    assert np.isnan(orc.weighted_spatial_mean(np.full((7, 4), np.nan), lat, 4))
