@@ -17,7 +17,9 @@ defs = [[3, 0, 0], [3, 1, 1], [4, 0, 0], [4, 1, 1], [5, 0, 0], [5, 1, 1]]
 dm = cal.build_doy_map(dates); north, south, _ = cal.hemisphere_season_tables(dates)
 hemi = (np.arange(n) % 2).astype(np.uint8)
 core.compute_percentiles(x[:64], ti, cols, q)  # warm-up (library init)
+thr = met = None
 for name, arr in (("time-contiguous [cells][T]", x), ("time-major [T][cells]", xt.T)):
+    del thr, met   # releasing 2 GB of results is not part of the next call
     t0 = time.perf_counter(); thr = core.compute_percentiles(arr, ti, cols, q); t1 = time.perf_counter()
     met = core.compute_heatwave_metrics(arr, thr, dm, defs, north, south, hemi); t2 = time.perf_counter()
     print(f"{name}: thresholds {n*T/(t1-t0):.3e} cell-days/s ({t1-t0:.2f} s), metrics {n*T/(t2-t1):.3e} cell-days/s ({t2-t1:.2f} s)")
