@@ -57,6 +57,7 @@ SIGNATURES = {
     "hdp_metrics_plan_reserve": (C.c_int, [vp, i64]),
     "hdp_metrics_f32_dev": (C.c_int, [vp, vp, vp, i64, vp, i64, vp, vp]),
     "hdp_metrics_f32": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, vp]),
+    "hdp_metrics_f32_planes_i64": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, vp]),
     "hdp_index_heatwaves": (C.c_int, [vp, i64, i64, i64, i64, i64, vp]),
     "hdp_season_metrics": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
     "hdp_indicate_hot_days": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),

@@ -68,7 +68,7 @@ def compute_percentiles_table(x, window_samples, percentiles):
 
 # ---- metrics ------------------------------------------------------------------------
 
-def compute_heatwave_metrics(x, thresholds, doy_map, hw_definitions, north, south, is_south):
+def compute_heatwave_metrics(x, thresholds, doy_map, hw_definitions, north, south, is_south, planes=False):
     """compute_heatwave_metrics (metric.py:304-341) for every (percentile, definition,
     series) in one pass over the measure.
 
@@ -90,10 +90,21 @@ def compute_heatwave_metrics(x, thresholds, doy_map, hw_definitions, north, sout
     D, Y = defs.shape[0], north.shape[0]
     if dm.size != T or hemi.size != n or south.shape[0] != Y:
         raise ValueError("inconsistent table sizes")
-    out = np.zeros((P, D, n, 4, Y), dtype=np.int16)
-    _lib.check(lib.hdp_metrics_f32(_ptr(x), n, T, sc, st, _ptr(thr), n_thr, n_doy, P, _ptr(dm),
-                                   _ptr(defs), D, _ptr(north), _ptr(south), _ptr(hemi), Y, _ptr(out)))
+    if planes:
+        out = np.zeros((4, P, D, n, Y), dtype=np.int64)
+        fn = lib.hdp_metrics_f32_planes_i64
+    else:
+        out = np.zeros((P, D, n, 4, Y), dtype=np.int16)
+        fn = lib.hdp_metrics_f32
+    _lib.check(fn(_ptr(x), n, T, sc, st, _ptr(thr), n_thr, n_doy, P, _ptr(dm), _ptr(defs), D, _ptr(north),
+                  _ptr(south), _ptr(hemi), Y, _ptr(out)))
     return out
+
+
+def compute_heatwave_metric_planes(x, thresholds, doy_map, hw_definitions, north, south, is_south):
+    """The same pass, returned as int64 [4, P, D, n_series, Y]: one contiguous plane per output variable
+    (HWF, HWN, HWD, HWA) in the dims and dtype compute_individual_metrics hands to xarray (metric.py:418-431)."""
+    return compute_heatwave_metrics(x, thresholds, doy_map, hw_definitions, north, south, is_south, planes=True)
 
 
 # ---- unit-level mirrors of the njit helpers (metric.py:11-172, 280-301) ----------------

@@ -450,10 +450,13 @@ int hdp_metrics_f32_dev(const hdp_metrics_plan *plan, const float *x_dev, const 
   return launch_metrics(plan, x_dev, thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev, pick(stream));
 }
 
-int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
-                    const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
-                    const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
-                    const int64_t *south, const uint8_t *is_south, int64_t Y, int16_t *out) {
+// Host-pointer metrics call; `planes` selects the result form:
+//   false  int16 [P][D][n_cells][4][Y]   the reference's gufunc block order (hdp_metrics_f32)
+//   true   int64 [4][P][D][n_cells][Y]   one plane per output variable (hdp_metrics_f32_planes_i64)
+static int metrics_host(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
+                        const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                        const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
+                        const int64_t *south, const uint8_t *is_south, int64_t Y, void *out, bool planes) {
   HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
   HDP_REQUIRE(n_cells >= 0 && n_thr_cells > 0, HDP_EINVAL, "bad cell counts");
   HDP_REQUIRE(n_cells == 0 || (x && thr && is_south && (out || Y == 0)), HDP_EINVAL, "NULL buffer");
@@ -481,13 +484,14 @@ int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_c
   }
   HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
   HDP_HIP_TRY(dsouth.alloc(size_t(chunk)));
+  const size_t esz = planes ? 8 : 2;  // bytes per value of the result
   HDP_HIP_TRY(dout.alloc(size_t(4) * P * D * chunk * Y * 2));
-  HDP_HIP_TRY(dref.alloc(size_t(4) * P * D * chunk * Y * 2));
+  HDP_HIP_TRY(dref.alloc(size_t(4) * P * D * chunk * Y * esz));
   SeriesUploader up;
   rc = up.prepare(x, n_cells, T, stride_cell, stride_time, whole_matrix_limit(), g_stream);
   if (rc != HDP_OK) return rc;
   ResultPrefault pre;
-  pre.start(out, size_t(P) * D * n_cells * 4 * Y * 2);  // the whole result, ahead of the first download
+  pre.start(out, size_t(P) * D * n_cells * 4 * Y * esz);  // the whole result, ahead of the first download
   for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
     const int64_t nc = std::min(chunk, n_cells - c0);
     rc = up.upload(x, c0, nc, T, stride_cell, stride_time, dx.as<float>(), g_stream);
@@ -499,15 +503,36 @@ int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_c
     rc = launch_metrics(plan, dx.as<float>(), thr_base, ntc, dsouth.as<uint8_t>(), nc, dout.as<int16_t>(),
                         g_stream);
     if (rc != HDP_OK) return rc;
-    rc = launch_metrics_repack(dout.as<int16_t>(), P, D, nc, Y, dref.as<int16_t>(), g_stream);
+    rc = planes ? launch_metrics_planes_i64(dout.as<int16_t>(), P, D, nc, Y, dref.as<int64_t>(), g_stream)
+                : launch_metrics_repack(dout.as<int16_t>(), P, D, nc, Y, dref.as<int16_t>(), g_stream);
     if (rc != HDP_OK) return rc;
-    // the chunk's [P*D][nc][4][Y] rows go straight to their places in out [P*D][n_cells][4][Y]
+    // the chunk's rows go straight to their places in the result: [P*D] rows of [nc][4][Y] into
+    // [P*D][n_cells][4][Y], or [4*P*D] rows of [nc][Y] into [4*P*D][n_cells][Y]
+    const size_t row_vals = planes ? size_t(Y) : size_t(4) * Y;
+    const size_t n_rows = (planes ? size_t(4) : size_t(1)) * P * D;
     pre.wait();
-    HDP_HIP_TRY(hipMemcpy2DAsync(out + c0 * 4 * Y, size_t(n_cells) * 4 * Y * 2, dref.p, size_t(nc) * 4 * Y * 2,
-                                 size_t(nc) * 4 * Y * 2, size_t(P) * D, hipMemcpyDeviceToHost, g_stream));
+    HDP_HIP_TRY(hipMemcpy2DAsync(static_cast<char *>(out) + size_t(c0) * row_vals * esz, size_t(n_cells) * row_vals * esz,
+                                 dref.p, size_t(nc) * row_vals * esz, size_t(nc) * row_vals * esz, n_rows,
+                                 hipMemcpyDeviceToHost, g_stream));
     HDP_HIP_TRY(hipStreamSynchronize(g_stream));
   }
   return HDP_OK;
+}
+
+int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
+                    const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                    const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
+                    const int64_t *south, const uint8_t *is_south, int64_t Y, int16_t *out) {
+  return metrics_host(x, n_cells, T, stride_cell, stride_time, thr, n_thr_cells, n_doy, P, doy_map, defs, D, north,
+                      south, is_south, Y, out, false);
+}
+
+int hdp_metrics_f32_planes_i64(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
+                               const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                               const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
+                               const int64_t *south, const uint8_t *is_south, int64_t Y, int64_t *out) {
+  return metrics_host(x, n_cells, T, stride_cell, stride_time, thr, n_thr_cells, n_doy, P, doy_map, defs, D, north,
+                      south, is_south, Y, out, true);
 }
 
 // ---- unit-level mirrors ---------------------------------------------------------------------------------

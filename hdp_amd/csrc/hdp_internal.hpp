@@ -166,6 +166,9 @@ int launch_swap_last2_f64(const double *src_dev, int64_t n, int64_t A, int64_t B
 int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,
                           int16_t *ref_layout, hipStream_t stream);
 
+int launch_metrics_planes_i64(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,
+                              int64_t *planes, hipStream_t stream);
+
 // numba rank arithmetic for one quantile over n samples; returns HDP_EQUANT for q
 // outside [0,1] (or NaN).  k_lo/k_hi are 0-based ASCENDING order-statistic indices.
 int quantile_param(double q, int64_t n, QuantileParam *qp, int64_t *k_lo, int64_t *k_hi);

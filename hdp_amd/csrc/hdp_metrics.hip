@@ -1060,6 +1060,21 @@ __global__ void metrics_repack_kernel(const int16_t *__restrict__ src, int64_t P
   }
 }
 
+// device layout [4][P][D][Y][n] int16 -> metric-major planes [4][P][D][n][Y] int64: the four output variables of
+// compute_individual_metrics (metric.py:418-431: int64, dims (percentile, definition, cells..., time)) as they
+// are handed to xarray, so the host side neither widens nor regroups the result
+__global__ void metrics_planes_i64_kernel(const int16_t *__restrict__ src, int64_t MPD, int64_t n, int64_t Y,
+                                          long long *__restrict__ dst) {
+  const int64_t total = MPD * n * Y;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total;
+       i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t y = i % Y;
+    const int64_t c = (i / Y) % n;
+    const int64_t mpd = i / (Y * n);
+    dst[i] = (long long)src[(mpd * Y + y) * n + c];
+  }
+}
+
 // ---- unit-level mirrors of the njit helpers --------------------------------------------------
 
 // metric.py:280-301
@@ -1657,6 +1672,16 @@ int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64
   if (total == 0) return HDP_OK;
   hipLaunchKernelGGL(metrics_repack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, dev_layout,
                      P * D, n_cells, Y, ref_layout);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+int launch_metrics_planes_i64(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,
+                              int64_t *planes, hipStream_t stream) {
+  const int64_t total = 4 * P * D * n_cells * Y;
+  if (total == 0) return HDP_OK;
+  hipLaunchKernelGGL(metrics_planes_i64_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, dev_layout,
+                     4 * P * D, n_cells, Y, reinterpret_cast<long long *>(planes));
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
 }

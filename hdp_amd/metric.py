@@ -93,13 +93,14 @@ def compute_individual_metrics(measure, threshold, hw_definitions, include_thres
     lat_b = (lat < 0).reshape([-1 if d == "lat" else 1 for d in proc_dims])   # metric.py:249: lat == 0 is north
     is_south = np.broadcast_to(lat_b, shape_cells).reshape(-1).astype(np.uint8)
 
-    raw = core.compute_heatwave_metrics(x2d, thr3, doy_map, hw_definitions, north, south, is_south)
+    # int64 planes [metric][P][D][series][Y] (int, as test_workflow.py:57), widened and regrouped on the device
+    planes = core.compute_heatwave_metric_planes(x2d, thr3, doy_map, hw_definitions, north, south, is_south)
     D, Y = len(hw_definitions), north.shape[0]
-    raw = raw.astype(np.int64).reshape((P, D) + tuple(proc_shape) + (4, Y))   # int, as test_workflow.py:57
-    # back to the measure's own dim order
-    src = ["percentile", "definition"] + proc_dims + ["metric", "year"]
-    dst = ["percentile", "definition"] + other_dims + ["metric", "year"]
-    raw = np.moveaxis(raw, [src.index(d) for d in dst], range(len(dst)))
+    planes = planes.reshape((4, P, D) + tuple(proc_shape) + (Y,))
+    # back to the measure's own dim order (a view; only the member dim ever moves)
+    src = ["metric", "percentile", "definition"] + proc_dims + ["year"]
+    dst = ["metric", "percentile", "definition"] + other_dims + ["year"]
+    planes = np.moveaxis(planes, [src.index(d) for d in dst], range(len(dst)))
 
     stamps = np.array(jan1_stamps(years, times[0]), dtype=object)
     coords = {k: np.asarray(measure.coords[k].values) for k in measure.coords if k != "time" and k in other_dims}
@@ -107,9 +108,8 @@ def compute_individual_metrics(measure, threshold, hw_definitions, include_thres
     coords["definition"] = [f"{d[0]}-{d[1]}-{d[2]}" for d in hw_definitions]
     coords["percentile"] = np.asarray(threshold.coords["percentile"].values)
     out_dims = ["percentile", "definition"] + other_dims + ["time"]
-    m_axis = dst.index("metric")
     ds = xr.Dataset(
-        {name: xr.DataArray(np.ascontiguousarray(np.take(raw, i, axis=m_axis)), dims=out_dims, coords=coords)
+        {name: xr.DataArray(planes[i], dims=out_dims, coords=coords)
          for i, name in enumerate(("HWF", "HWN", "HWD", "HWA"))})
     ds.attrs.update({
         "description": f"Heatwave metric dataset generated by Heatwave Diagnostics Package (HDP v{get_version()})",

@@ -167,6 +167,16 @@ int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T,
                     const int64_t *north, const int64_t *south,
                     const uint8_t *is_south, int64_t Y, int16_t *out);
 
+/* Same call; out [4][P][D][n_cells][Y] int64: one contiguous plane per output variable HWF, HWN, HWD, HWA in
+ * the dims compute_individual_metrics gives them, (percentile, definition, cells..., time), and in its dtype
+ * (metric.py:418-431) -- widened and regrouped on the device, downloaded straight into place. */
+int hdp_metrics_f32_planes_i64(const float *x, int64_t n_cells, int64_t T,
+                               int64_t stride_cell, int64_t stride_time,
+                               const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                               const int64_t *doy_map, const int64_t *defs, int64_t D,
+                               const int64_t *north, const int64_t *south,
+                               const uint8_t *is_south, int64_t Y, int64_t *out);
+
 /* ---- unit-level mirrors of the njit helpers (for the known-answer tests) ---- */
 
 /* metric.py:11-60: hot [n_series][T] u8 -> ids [n_series][T] int64 */

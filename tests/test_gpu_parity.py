@@ -670,3 +670,15 @@ def test_weighted_spatial_mean_matches_numpy_restatement():
         _lib.check(lib.hdp_sync(None))
         out = dout.to_host()
         assert np.allclose(out, (rows.astype(np.float64) * w).sum(axis=1) / w.sum(), rtol=1e-12, atol=0)
+
+
+def test_metric_planes_entry_point_matches_block_order():
+    """hdp_metrics_f32_planes_i64: int64 [4][P][D][series][Y] planes == the int16 block-order result regrouped;
+    several chunks (ragged last one) through the 2-D downloads, shared member thresholds."""
+    defs = [[3, 0, 0], [2, 1, 1], [4, 2, 0]]
+    case = _random_metrics_case(77, 6, 45, 3, defs, trend=1.1)
+    blocks = core.compute_heatwave_metrics(*case)
+    planes = core.compute_heatwave_metric_planes(*case)
+    assert planes.dtype == np.int64 and planes.shape == (4,) + blocks.shape[:3] + blocks.shape[4:]
+    assert np.array_equal(planes, np.moveaxis(blocks.astype(np.int64), 3, 0))
+    assert np.array_equal(np.moveaxis(planes, 0, 3), orc.compute_metrics_cells(*case))

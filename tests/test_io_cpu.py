@@ -40,6 +40,8 @@ def store(monkeypatch):
 
     monkeypatch.setattr(core, "compute_percentiles", fake_percentiles)
     monkeypatch.setattr(core, "compute_heatwave_metrics", fake_metrics)
+    monkeypatch.setattr(core, "compute_heatwave_metric_planes",
+                        lambda *a: np.ascontiguousarray(np.moveaxis(fake_metrics(*a).astype(np.int64), 3, 0)))
     return files, opened
 
 
