@@ -65,6 +65,13 @@ struct ResultPrefault {
   void start(void *p, size_t bytes) {
     wait();
     if (!p || bytes < (size_t(8) << 20)) return;
+    try {
+      launch(p, bytes);
+    } catch (...) {  // no helper thread available: the copy takes the faults itself, as before
+      pending = std::future<void>();
+    }
+  }
+  void launch(void *p, size_t bytes) {
     pending = std::async(std::launch::async, [p, bytes] {
       constexpr int kThreads = 4;
       constexpr size_t kPage = 4096;
@@ -75,16 +82,26 @@ struct ResultPrefault {
       const size_t part = ((bytes / kThreads) + kPage - 1) & ~(kPage - 1);
       std::thread th[kThreads];
       int started = 0;
-      for (int k = 0; k < kThreads; ++k) {
+      for (int k = 1; k < kThreads; ++k) {  // this thread takes part 0 (and whatever could not get a thread)
         const size_t a = size_t(k) * part;
         if (a >= bytes) break;
-        th[started++] = std::thread(touch, base + a, std::min(part, bytes - a));
+        try {
+          th[started] = std::thread(touch, base + a, std::min(part, bytes - a));
+          ++started;
+        } catch (...) {
+          touch(base + a, std::min(part, bytes - a));
+        }
       }
+      touch(base, std::min(part, bytes));
       for (int k = 0; k < started; ++k) th[k].join();
     });
   }
   void wait() {
-    if (pending.valid()) pending.get();
+    if (!pending.valid()) return;
+    try {
+      pending.get();
+    } catch (...) {
+    }
   }
   ~ResultPrefault() { wait(); }
 };
