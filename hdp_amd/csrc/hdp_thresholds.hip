@@ -279,7 +279,9 @@ __device__ __forceinline__ void sort_column(float *col, int S, uint32_t *flag_ou
   uint32_t n_nan = 0, n_pos = 0, n_neg = 0;
 #pragma unroll
   for (int r = 0; r < EPL; ++r) {
-    const int e = lane * EPL + r;
+    // a sorting network does not care which slot an input starts in: read with consecutive lanes on consecutive
+    // words (conflict-free) although the sorted output is lane-major
+    const int e = r * 64 + lane;
     float x = (e < S) ? col[e] : -INFINITY;
     const bool is_nan = (x != x);
     const bool is_pos = (e < S) && (x == INFINITY);
@@ -683,12 +685,18 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
       while (nb > 0 && __ballot((ww >> (nb - 1)) != 0) == 0) --nb;
       for (int sb = nb - 1; sb >= 0; --sb) {
         const int stride = 1 << sb;
+        // all NC reads of a stride in flight before the first compare (the scheduler otherwise may pair every
+        // read with its own wait, which exposes the LDS latency NC times per stride: 147 k -> 222 k cycles per block)
+        int idx[NC], k[NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-          const int idx = min(pos[j] + stride, S + 1);  // the sentinel after the column is never above
-          const int k = colk[base[j] + idx];
-          pos[j] = (k > thr[j]) ? idx : pos[j];
+          idx[j] = min(pos[j] + stride, S + 1);  // the sentinel after the column is never above
+          k[j] = colk[base[j] + idx[j]];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) pos[j] = (k[j] > thr[j]) ? idx[j] : pos[j];
+        __builtin_amdgcn_sched_barrier(0);
       }
       int G = 0;
 #pragma unroll
