@@ -818,6 +818,7 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
       if (pd.debug & 1) {
       } else if (pd.W <= 4) select_rows<4>(pd, colk, flags, row0, nrows, tid, cell, out);
       else if (pd.W <= 8) select_rows<8>(pd, colk, flags, row0, nrows, tid, cell, out);
+      else if (pd.W == 15) select_rows<15>(pd, colk, flags, row0, nrows, tid, cell, out);  // the default radius 7
       else select_rows<16>(pd, colk, flags, row0, nrows, tid, cell, out);
     } else if (tid < nrows) {
       const int row = row0 + tid;
