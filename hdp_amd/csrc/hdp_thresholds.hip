@@ -1282,6 +1282,7 @@ static ThrVariant thr_variant(const hdp_threshold_plan *plan, int debug) {
   // HDP_THR_SELECT=0/1 forces the choice for tests
   v.select = !v.pipe && (plan->W <= 16) && (plan->steps_top + plan->steps_bot >= 512);
   if (const char *env = getenv("HDP_THR_SELECT")) v.select = !v.pipe && (plan->W <= 16) && atoi(env) != 0;
+  if (plan->select_only) v.select = true;  // the plan's LDS image has no room for merge heads
   return v;
 }
 
@@ -1475,12 +1476,20 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   pl->steps_bot = bot.empty() ? 0 : bot.back().rank + 1;
 
   // choose rows per block against the LDS budget
+  // Plans that can only ever run the rank selection (more than 128 samples per column, deep ranks, W <= 16, and
+  // HDP_THR_SELECT not 0 when the plan is made) need no merge heads in LDS: two more columns per block at S = 1000.
+  {
+    const char *env = getenv("HDP_THR_SELECT");
+    pl->select_only = S > 128 && W <= 16 && (pl->steps_top + pl->steps_bot >= 512) && !(env && atoi(env) == 0);
+  }
   auto lds_for = [&](int rows, int ncols) -> size_t {
     const int RP = (rows + 63) & ~63;
     size_t b = (size_t(ncols) * spad * 4 + 15) & ~size_t(15);
     b += 2 * ((size_t(ncols) * 4 + 15) & ~size_t(15));  // census words (x2: pipelined kernel)
-    b += size_t(pl->Wp) * RP * 4;       // heads
-    b += size_t(pl->Wp) * RP * 4;       // position | slot payloads
+    if (!pl->select_only) {
+      b += size_t(pl->Wp) * RP * 4;  // heads
+      b += size_t(pl->Wp) * RP * 4;  // position | slot payloads
+    }
     b += (size_t(rows) * W * 2 + 15) & ~size_t(15);  // window column lists (pipelined kernel)
     return b;
   };
