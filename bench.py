@@ -217,41 +217,47 @@ def main():
     # ---- pre-step: fused Celsius -> heat index -> Celsius kernel, reported beside `value`
     pre_step = None
     if rank == 0:
-        n_el = int(min(bc * T, thr.numel() // 4, out.numel() // 2, 1 << 30)) & ~3
-        e0, e1 = lib.hdp_event_create(), lib.hdp_event_create()
-        rh_buf = thr[: n_el * 4]      # reuse resident scratch as (arbitrary) humidity / output operands
-        lib.hdp_heat_index_celsius_f32_dev(xm.data_ptr(), rh_buf.data_ptr(), n_el, out.data_ptr(), stream)
-        lib.hdp_event_record(e0, stream)
-        reps = 5
-        for _ in range(reps):
-            _lib.check(lib.hdp_heat_index_celsius_f32_dev(xm.data_ptr(), rh_buf.data_ptr(), n_el, out.data_ptr(), stream))
-        lib.hdp_event_record(e1, stream)
-        hms = ctypes.c_float()
-        _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(hms)))
-        gbps = 12.0 * n_el * reps / (hms.value * 1e-3) / 1e9      # 2 x 4 B read + 4 B written per element
-        pre_step = {"kernel": "heat_index_kernel<celsius>", "elements": n_el, "ms": hms.value / reps,
-                    "GBps": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
+        try:
+            n_el = int(min(bc * T, thr.numel() // 4, out.numel() // 2, 1 << 30)) & ~3
+            e0, e1 = lib.hdp_event_create(), lib.hdp_event_create()
+            rh_buf = thr[: n_el * 4]      # reuse resident scratch as (arbitrary) humidity / output operands
+            lib.hdp_heat_index_celsius_f32_dev(xm.data_ptr(), rh_buf.data_ptr(), n_el, out.data_ptr(), stream)
+            lib.hdp_event_record(e0, stream)
+            reps = 5
+            for _ in range(reps):
+                _lib.check(lib.hdp_heat_index_celsius_f32_dev(xm.data_ptr(), rh_buf.data_ptr(), n_el, out.data_ptr(), stream))
+            lib.hdp_event_record(e1, stream)
+            hms = ctypes.c_float()
+            _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(hms)))
+            gbps = 12.0 * n_el * reps / (hms.value * 1e-3) / 1e9      # 2 x 4 B read + 4 B written per element
+            pre_step = {"kernel": "heat_index_kernel<celsius>", "elements": n_el, "ms": hms.value / reps,
+                        "GBps": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
+        except Exception as e:   # reported beside `value`; must not cost the bench line
+            pre_step = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- post-step: latitude-weighted spatial mean of the resident int16 metrics, one row per
     # (metric, percentile, definition, season) over this band's series; reported beside `value`
     post_step = None
     if rank == 0:
-        n_rows, n_ser = 4 * P * D * int(Yp), M * bc
-        w_dev = torch.from_numpy(np.cos(np.deg2rad(np.tile(lat_cells[:bc], M).astype(np.float64)))).to(dev)
-        mean_dev = torch.empty(n_rows, dtype=torch.float64, device=dev)
-        e0, e1 = lib.hdp_event_create(), lib.hdp_event_create()
-        _lib.check(lib.hdp_weighted_mean_i16_dev(out.data_ptr(), n_rows, n_ser, w_dev.data_ptr(), mean_dev.data_ptr(), stream))
-        lib.hdp_event_record(e0, stream)
-        reps = 3
-        for _ in range(reps):
+        try:
+            n_rows, n_ser = 4 * P * D * int(Yp), M * bc
+            w_dev = torch.from_numpy(np.cos(np.deg2rad(np.tile(lat_cells[:bc], M).astype(np.float64)))).to(dev)
+            mean_dev = torch.empty(n_rows, dtype=torch.float64, device=dev)
+            e0, e1 = lib.hdp_event_create(), lib.hdp_event_create()
             _lib.check(lib.hdp_weighted_mean_i16_dev(out.data_ptr(), n_rows, n_ser, w_dev.data_ptr(), mean_dev.data_ptr(), stream))
-        lib.hdp_event_record(e1, stream)
-        wms = ctypes.c_float()
-        _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(wms)))
-        gbps = (2.0 * n_rows * n_ser + 8.0 * n_ser + 8.0 * n_rows) * reps / (wms.value * 1e-3) / 1e9
-        post_step = {"kernel": "weighted_rows_mean_i16x8_kernel", "rows": n_rows, "series": n_ser,
-                     "ms": wms.value / reps, "GBps": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
-        del w_dev, mean_dev
+            lib.hdp_event_record(e0, stream)
+            reps = 3
+            for _ in range(reps):
+                _lib.check(lib.hdp_weighted_mean_i16_dev(out.data_ptr(), n_rows, n_ser, w_dev.data_ptr(), mean_dev.data_ptr(), stream))
+            lib.hdp_event_record(e1, stream)
+            wms = ctypes.c_float()
+            _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(wms)))
+            gbps = (2.0 * n_rows * n_ser + 8.0 * n_ser + 8.0 * n_rows) * reps / (wms.value * 1e-3) / 1e9
+            post_step = {"kernel": "weighted_rows_mean_i16x8_kernel", "rows": n_rows, "series": n_ser,
+                         "ms": wms.value / reps, "GBps": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
+            del w_dev, mean_dev
+        except Exception as e:
+            post_step = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- RCCL all-gather of the metrics (reassembly step of north_star), reported separately ------------
     allgather = None
@@ -287,41 +293,44 @@ def main():
     cpu = None
     parity = None
     if rank == 0 and not args.no_cpu_baseline:
-        from oracle import c_oracle
-        cores = c_oracle.max_threads()
-        win = cal.expand_window_table(time_index, cols)
-        xb_h = lambda n: xb[: n * M * T * 4].cpu().numpy().view(np.float32).reshape(n, M * T)  # noqa: E731
-        # the M members of the first n cells, member-major like the device buffer
-        xm_h = lambda n: (xm.view(torch.float32).view(M, bc, T)[:, :n].cpu().numpy()  # noqa: E731
-                          .reshape(M * n, T))
-        thr_m = lambda th: np.concatenate([th] * M)                                     # noqa: E731
-        hemi_m = lambda n: np.tile((lat_cells[:n] < 0).astype(np.uint8), M)             # noqa: E731
-        n0 = min(bc, cores)
-        tc = time.perf_counter()
-        th0 = c_oracle.thresholds(xb_h(n0), win, PERCENTILES)
-        c_oracle.metrics(xm_h(n0), thr_m(th0), doy_map, DEFINITIONS, north, south, hemi_m(n0))
-        per_round = time.perf_counter() - tc
-        rounds = int(max(1, min(64, args.cpu_seconds / max(per_round, 1e-3))))
-        ns = min(bc, n0 * rounds)
-        tc = time.perf_counter()
-        th_cpu = c_oracle.thresholds(xb_h(ns), win, PERCENTILES)
-        met_cpu = c_oracle.metrics(xm_h(ns), thr_m(th_cpu), doy_map, DEFINITIONS, north, south, hemi_m(ns))
-        cpu_s = time.perf_counter() - tc
-        cpu = None if world > 1 else {   # reported at N = 1 only (torchrun pins OMP_NUM_THREADS=1)
-            "value": 2.0 * ns * M * T / cpu_s, "unit": "cell-days/s", "cores": cores, "kind": "port",
-               "sample": f"first {ns} cells of band 0 of the same workload (T={T}, P={P}, D={D}), both passes, "
-                      f"{cpu_s:.1f} s; oracle/hdp_oracle.c (reference algorithm restated in C, OpenMP over cells)"}
-        # the same sample doubles as a parity spot-check of what the timed kernels produced (band 0 flags)
-        tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
-        mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[0].data_ptr(), M * bc, out.data_ptr(), stream)
-        torch.cuda.synchronize(dev)
-        # device layout [cell][P][n_doy] -> the reference's (cell, doy, percentile)
-        th_gpu = thr[: ns * n_doy * P * 8].cpu().numpy().view(np.float64).reshape(ns, P, n_doy).transpose(0, 2, 1)
-        # device layout [4][P][D][Y][series] -> the reference's (percentile, definition, series, metric, year)
-        out_gpu = out.view(4, P * D, Y, M, bc)[..., :ns].cpu().numpy()
-        met_gpu = np.transpose(out_gpu.reshape(4, P, D, Y, M * ns), (1, 2, 4, 0, 3)).astype(np.int64)
-        parity = {"cells": ns, "thresholds_bit_exact": bool(np.array_equal(th_gpu, th_cpu)),
-                  "metrics_bit_exact": bool(np.array_equal(met_gpu, met_cpu))}
+        try:
+            from oracle import c_oracle
+            cores = c_oracle.max_threads()
+            win = cal.expand_window_table(time_index, cols)
+            xb_h = lambda n: xb[: n * M * T * 4].cpu().numpy().view(np.float32).reshape(n, M * T)  # noqa: E731
+            # the M members of the first n cells, member-major like the device buffer
+            xm_h = lambda n: (xm.view(torch.float32).view(M, bc, T)[:, :n].cpu().numpy()  # noqa: E731
+                              .reshape(M * n, T))
+            thr_m = lambda th: np.concatenate([th] * M)                                     # noqa: E731
+            hemi_m = lambda n: np.tile((lat_cells[:n] < 0).astype(np.uint8), M)             # noqa: E731
+            n0 = min(bc, cores)
+            tc = time.perf_counter()
+            th0 = c_oracle.thresholds(xb_h(n0), win, PERCENTILES)
+            c_oracle.metrics(xm_h(n0), thr_m(th0), doy_map, DEFINITIONS, north, south, hemi_m(n0))
+            per_round = time.perf_counter() - tc
+            rounds = int(max(1, min(64, args.cpu_seconds / max(per_round, 1e-3))))
+            ns = min(bc, n0 * rounds)
+            tc = time.perf_counter()
+            th_cpu = c_oracle.thresholds(xb_h(ns), win, PERCENTILES)
+            met_cpu = c_oracle.metrics(xm_h(ns), thr_m(th_cpu), doy_map, DEFINITIONS, north, south, hemi_m(ns))
+            cpu_s = time.perf_counter() - tc
+            cpu = None if world > 1 else {   # reported at N = 1 only (torchrun pins OMP_NUM_THREADS=1)
+                "value": 2.0 * ns * M * T / cpu_s, "unit": "cell-days/s", "cores": cores, "kind": "port",
+                   "sample": f"first {ns} cells of band 0 of the same workload (T={T}, P={P}, D={D}), both passes, "
+                          f"{cpu_s:.1f} s; oracle/hdp_oracle.c (reference algorithm restated in C, OpenMP over cells)"}
+            # the same sample doubles as a parity spot-check of what the timed kernels produced (band 0 flags)
+            tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
+            mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[0].data_ptr(), M * bc, out.data_ptr(), stream)
+            torch.cuda.synchronize(dev)
+            # device layout [cell][P][n_doy] -> the reference's (cell, doy, percentile)
+            th_gpu = thr[: ns * n_doy * P * 8].cpu().numpy().view(np.float64).reshape(ns, P, n_doy).transpose(0, 2, 1)
+            # device layout [4][P][D][Y][series] -> the reference's (percentile, definition, series, metric, year)
+            out_gpu = out.view(4, P * D, Y, M, bc)[..., :ns].cpu().numpy()
+            met_gpu = np.transpose(out_gpu.reshape(4, P, D, Y, M * ns), (1, 2, 4, 0, 3)).astype(np.int64)
+            parity = {"cells": ns, "thresholds_bit_exact": bool(np.array_equal(th_gpu, th_cpu)),
+                      "metrics_bit_exact": bool(np.array_equal(met_gpu, met_cpu))}
+        except Exception as e:   # the checker must not cost the bench line
+            parity = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         line = {
