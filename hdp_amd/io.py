@@ -76,3 +76,29 @@ def concat_lat(parts):
     if len(parts) == 1:
         return parts[0]
     return backend().concat(parts, dim="lat")
+
+
+def block_slices(da, skip=("time",)):
+    """(dim, [(a, b), ...]) for the first dimension (other than ``skip``) along which ``da`` is stored in more than
+    one chunk -- a dask-backed xarray object exposes ``.chunks`` as per-dimension tuples of block lengths -- else
+    None.  The reference hands such blocks to ``map_blocks`` (threshold.py:138-161, metric.py:420-444); the adapters
+    walk them in order, so only one block of a lazily loaded variable is in host memory at a time."""
+    chunks = getattr(da, "chunks", None)
+    if not chunks:
+        return None
+    for dim, lens in zip(da.dims, chunks):
+        if dim in skip or lens is None or len(lens) < 2:
+            continue
+        edges, a = [], 0
+        for n in lens:
+            edges.append((a, a + int(n)))
+            a += int(n)
+        return dim, edges
+    return None
+
+
+def concat_dim(parts, dim):
+    """Datasets of consecutive blocks along ``dim`` -> one Dataset (attrs of the first block)."""
+    if len(parts) == 1:
+        return parts[0]
+    return backend().concat(parts, dim=dim)

@@ -53,6 +53,13 @@ def compute_individual_metrics(measure, threshold, hw_definitions, include_thres
 
     Output variables are int64 with dims (percentile, definition, <non-time dims of the
     measure in order>, time) where time holds one Jan-1 stamp per season year."""
+    blocks = hio.block_slices(measure, skip=("time", "member"))
+    if blocks is not None and blocks[0] in threshold.dims:
+        # lazily chunked measure: one block at a time with the matching slice of the thresholds (metric.py:444)
+        dim, edges = blocks
+        parts = [compute_individual_metrics(measure.isel(**{dim: slice(a, b)}), threshold.isel(**{dim: slice(a, b)}),
+                                            hw_definitions, include_threshold, check_variables) for a, b in edges]
+        return hio.concat_dim(parts, dim)
     xr = backend()
     times = np.asarray(measure.coords["time"].values)
     if check_variables:

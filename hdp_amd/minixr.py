@@ -16,6 +16,8 @@ import numpy as np
 
 
 class DataArray:
+    chunks = None   # xarray: per-dimension block lengths of a dask-backed array; tests may set it on an instance
+
     def __init__(self, data, dims=None, coords=None, name=None, attrs=None):
         self.values = np.asarray(data)
         if dims is None:

@@ -136,3 +136,29 @@ def test_metrics_io_matches_in_memory_call_and_bands(tmp_path, store):
 def test_io_without_xarray_fails_loudly(tmp_path):
     with pytest.raises(ImportError, match="needs xarray"):
         hdp_amd.threshold.compute_threshold_io(tmp_path / "base.nc", "temp", tmp_path / "out.nc", [0.9])
+
+
+def test_chunked_inputs_are_walked_block_by_block(store, monkeypatch):
+    """an input that exposes dask-style ``.chunks`` is processed one block at a time along its
+    first chunked non-time dimension (thresholds sliced alike for the metrics) and gives the same Datasets."""
+    base, warm, lon, lat, bdates, mdates = _grids()
+    q = [0.9, 0.95]
+    defs = [[3, 0, 0], [3, 1, 1]]
+    whole_thr = hdp_amd.threshold.compute_threshold(measure_dataset(base, lon, lat, bdates)["temp"], q)
+    bda = measure_dataset(base, lon, lat, bdates)["temp"]                  # dims (lon, lat, time)
+    bda.chunks = ((2,), (2, 2, 1), (bdates.size,))                          # three blocks along lat
+    sizes = []
+    real = core.compute_percentiles
+    monkeypatch.setattr(core, "compute_percentiles", lambda x, *a: (sizes.append(x.shape[0]), real(x, *a))[1])
+    thr = hdp_amd.threshold.compute_threshold(bda, q)
+    assert sizes == [4, 4, 2]                                               # lon x lat cells per block
+    same_dataset(thr, whole_thr)
+    mda = measure_dataset(warm, lon, lat, mdates)["temp"]
+    whole = hdp_amd.metric.compute_individual_metrics(mda, whole_thr["temp_threshold"], defs, check_variables=False)
+    mda.chunks = ((1, 1), (5,), (mdates.size,))                             # two blocks along lon
+    calls = []
+    real_m = core.compute_heatwave_metric_planes
+    monkeypatch.setattr(core, "compute_heatwave_metric_planes", lambda x, *a: (calls.append(x.shape[0]), real_m(x, *a))[1])
+    got = hdp_amd.metric.compute_individual_metrics(mda, whole_thr["temp_threshold"], defs, check_variables=False)
+    assert calls == [5, 5]
+    same_dataset(got, whole)
