@@ -297,6 +297,9 @@ __device__ __forceinline__ void store32(int16_t *dst, const uint32_t (&a)[8]) {
 // once per series and shared by the four waves, each of which converts every fourth 2048-day chunk.
 // With only ~15 KB of LDS per workgroup the CU holds ~40 waves, so this streaming kernel hides HBM
 // latency by occupancy; the state-machine kernel that follows then needs no thresholds at all.
+// CW = 64-day words per wave and chunk (lane w of an accumulator holds word w): 32, or 16 for records of at most 64 words
+// (T <= 4096), where 32-word chunks would leave two of the four waves without work.
+template <int CW>
 __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__restrict__ x,
                                                      const double *__restrict__ thr, int64_t n_thr_cells,
                                                      int64_t n_cells) {
@@ -320,16 +323,16 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
   const int Tp = n_words * 64;
   unsigned long long *brow = md.bits_g + cell * md.P * int64_t(md.words_pad);
   static_assert(kQB == 4, "one float4 of thresholds per day");
-  for (int w0 = wave * kCW; w0 < n_words; w0 += 4 * kCW) {
-    float xr[kCW];
-    uint32_t dr[kCW / 2];
+  for (int w0 = wave * CW; w0 < n_words; w0 += 4 * CW) {
+    float xr[CW];
+    uint32_t dr[CW / 2];
 #pragma unroll
-    for (int w = 0; w < kCW; ++w) {
+    for (int w = 0; w < CW; ++w) {
       const int t = (w0 + w) * 64 + lane;
       xr[w] = (t < md.T) ? xc[t] : -INFINITY;
     }
 #pragma unroll
-    for (int w = 0; w < kCW; w += 2) {
+    for (int w = 0; w < CW; w += 2) {
       const int t = (w0 + w) * 64 + lane;
       const uint32_t a = (t < Tp) ? md.doy_map[t] : 0u;
       const uint32_t b = (t + 64 < Tp) ? md.doy_map[t + 64] : 0u;
@@ -343,8 +346,8 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
       const int pq4 = PQ / 4;
       float4 tc = t4[(dr[0] & 0xffffu) * pq4], tn = tc;
 #pragma unroll
-      for (int w = 0; w < kCW; ++w) {
-        if (w + 1 < kCW) {
+      for (int w = 0; w < CW; ++w) {
+        if (w + 1 < CW) {
           const int dn = ((w + 1) & 1) ? (dr[(w + 1) / 2] >> 16) : (dr[(w + 1) / 2] & 0xffffu);
           tn = t4[dn * pq4];
         }
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
       }
 #pragma unroll
       for (int j = 0; j < kQB; ++j)
-        if (q0 + j < md.P && lane < kCW)
+        if (q0 + j < md.P && lane < CW)
           brow[int64_t(q0 + j) * md.words_pad + w0 + lane] = ((unsigned long long)hi[j] << 32) | lo[j];
     }
   }
@@ -1558,9 +1561,10 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   }
   md.bits_g = plan->bits_scratch.as<unsigned long long>();
   const size_t lds_a = (size_t((md.P + kQB - 1) / kQB * kQB) * md.n_doy * 4 + 15) & ~size_t(15);
+  const bool short_record = ((md.T + 63) >> 6) <= 64;  // at most two 32-word chunks: use 16-word chunks, all four waves
   if (split) {
     HDP_REQUIRE(lds_a <= kLdsPerCU - 1024, HDP_EUNSUP, "too many percentiles for the exceedance kernel");
-    HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(exceed_kernel),
+    HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(short_record ? exceed_kernel<16> : exceed_kernel<32>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
   }
   auto kern_rows = split ? metrics_kernel_uniform<true> : (uniform ? metrics_kernel_uniform<false> : metrics_kernel_general);
@@ -1598,7 +1602,10 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     if (split) {
       // this half of the scratch is free once the state machine of batch b - 2 has read it
       if (overlap && b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_state[half], 0));
-      hipLaunchKernelGGL(exceed_kernel, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
+      if (short_record)
+        hipLaunchKernelGGL(exceed_kernel<16>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
+      else
+        hipLaunchKernelGGL(exceed_kernel<32>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
       HDP_HIP_TRY(hipGetLastError());
       if (overlap) {
         HDP_HIP_TRY(hipEventRecord(plan->ev_exceed[half], sx));
