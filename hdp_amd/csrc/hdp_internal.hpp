@@ -92,6 +92,7 @@ struct hdp_threshold_plan {
   hdp::DevBuf cols_local;  // uint16 [n_doy][W] local column of each window member
   hdp::DevBuf qparam;      // QuantileParam [P]
   hdp::DevBuf tgt_top, tgt_bot;  // int2 (rank, slot) sorted by rank
+  hdp::DevBuf blk_sort_off, sort_slots;  // per block: the LDS column slots it loads and sorts
   // pipelined kernel (S <= 128): producer waves gather + sort the next block in registers while
   // the merging waves work on the current one
   bool pipe = false;

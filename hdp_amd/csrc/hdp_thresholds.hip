@@ -37,6 +37,7 @@ struct ThrDev {
   const uint16_t *cols_local;
   const QuantileParam *qp;
   const int2 *tgt_top, *tgt_bot;
+  const int32_t *blk_sort_off, *sort_slots;  // one-workgroup-per-cell kernel: LDS column slots a block (re)loads and sorts
   const int32_t *tix, *blk_col_off;  // pipelined kernel: (block column, sample) -> time index
   const float *ninf;                 // four -inf words (what a slot without a sample loads)
   const int32_t *blk_grp_off, *grp_col;  // 16-byte gathers: first column of every group of four, per block
@@ -772,9 +773,13 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
     unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0;
     if (pd.debug & 8) t_a = __builtin_readcyclecounter();
     // 1. sentinels + load
+    // `ncols` LDS column slots are (re)loaded and sorted by this block; the others keep the sorted columns of
+    // earlier blocks (ring schedule of select-only plans; everywhere else the list is 0 .. ncols-1)
+    const int32_t *slots = pd.sort_slots + pd.blk_sort_off[b];
     for (int i = tid; i < ncols; i += kThrThreads) {
-      colbuf[i * pd.S_pad] = __int_as_float(kKeyMax);          // below every ascending walk
-      colbuf[i * pd.S_pad + pd.S + 1] = __int_as_float(kKeyMin);  // below every descending walk
+      const int lc = slots[i];
+      colbuf[lc * pd.S_pad] = __int_as_float(kKeyMax);          // below every ascending walk
+      colbuf[lc * pd.S_pad + pd.S + 1] = __int_as_float(kKeyMin);  // below every descending walk
     }
     if (!(pd.debug & 4)) {
       // batches of kLoadBatch independent (list entry -> sample -> LDS) chains per thread: all list
@@ -805,8 +810,10 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
       else if (pd.S <= 64) sort_block_rows<8>(colbuf, pd.S_pad, pd.S, ncols, flags, wave, nwaves, lane);
       else sort_block_rows<16>(colbuf, pd.S_pad, pd.S, ncols, flags, wave, nwaves, lane);
     } else {
-      for (int lc = wave; lc < ncols; lc += nwaves)
+      for (int i = wave; i < ncols; i += nwaves) {
+        const int lc = slots[i];
         sort_column<EPL>(colbuf + lc * pd.S_pad + 1, pd.S, &flags[lc], lane);
+      }
     }
     __syncthreads();
     if (pd.debug & 8) t_c = __builtin_readcyclecounter();
@@ -1299,10 +1306,11 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
              plan->n_merge, plan->rows_per_block, plan->n_blocks, plan->lds_bytes);
   else
     snprintf(buf, sizeof buf,
-             "thresholds_kernel<EPL=%d,%s> (one workgroup per cell: LDS columns, wave sort, %s; %d rows x %d blocks, "
+             "thresholds_kernel<EPL=%d,%s> (one workgroup per cell: LDS columns, wave sort, %s; <= %d rows x %d blocks%s, "
              "%zu B LDS)",
              plan->epl, v.select ? "select" : "merge", v.select ? "rank selection per (row, rank)" : "W-way merge per row",
-             plan->rows_per_block, plan->n_blocks, plan->lds_bytes);
+             plan->rows_per_block, plan->n_blocks, plan->select_only ? " over a ring of resident columns" : "",
+             plan->lds_bytes);
   return buf;
 }
 
@@ -1322,6 +1330,8 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.qp = plan->qparam.as<QuantileParam>();
   pd.tgt_top = plan->tgt_top.as<int2>();
   pd.tgt_bot = plan->tgt_bot.as<int2>();
+  pd.blk_sort_off = plan->blk_sort_off.as<int32_t>();
+  pd.sort_slots = plan->sort_slots.as<int32_t>();
   pd.n_doy = (int)plan->n_doy;
   pd.S = (int)plan->S;
   pd.W = (int)plan->W;
@@ -1597,11 +1607,97 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   pl->n_blocks = int((n_doy + rows - 1) / rows);
 
   // per-block tables
-  std::vector<int32_t> row0s, nrows, ncols, loff, llen, coff, cdoy;
+  std::vector<int32_t> row0s, nrows, ncols, loff, llen, coff, cdoy, soff, sslots;
   std::vector<int2> list;
   std::vector<uint16_t> cl(size_t(n_doy) * W);
   std::vector<int> set, local(n_doy);
-  for (int b = 0; b < pl->n_blocks; ++b) {
+  if (pl->select_only) {
+    // Ring schedule: the LDS image is `cm` column slots that persist across the blocks of a cell.  A block loads
+    // and sorts only the columns its rows need that are not resident yet, into the slots of columns no later row
+    // needs soonest (Belady); adjacent windows share all but one column, so after the first block a block of R rows
+    // brings in about R columns instead of R + W - 1.
+    const int C = cm, n_waves = hdp::kThrThreads / 64;
+    std::vector<std::vector<int>> rows_of(n_doy);
+    for (int r = 0; r < n_doy; ++r)
+      for (int64_t j = 0; j < W; ++j) {
+        std::vector<int> &v = rows_of[cols[int64_t(r) * W + j]];
+        if (v.empty() || v.back() != r) v.push_back(r);
+      }
+    std::vector<int> slot_of(n_doy, -1), col_in(C, -1);
+    auto next_use = [&](int c, int from_row) {
+      const std::vector<int> &v = rows_of[c];
+      auto it = std::lower_bound(v.begin(), v.end(), from_row);
+      return it == v.end() ? (1 << 30) : *it;
+    };
+    auto needed_for = [&](int r0, int nr, std::vector<int> &need, std::vector<int> &fresh) {
+      need.clear();
+      fresh.clear();
+      std::vector<char> seen(n_doy, 0);
+      for (int r = r0; r < r0 + nr; ++r)
+        for (int64_t j = 0; j < W; ++j) {
+          const int c = cols[int64_t(r) * W + j];
+          if (seen[c]) continue;
+          seen[c] = 1;
+          need.push_back(c);
+          if (slot_of[c] < 0) fresh.push_back(c);
+        }
+    };
+    int r0 = 0, n_steps = 0;
+    std::vector<int> need, fresh;
+    while (r0 < n_doy) {
+      // as many rows as fit; among the three largest fitting counts prefer one whose new columns fill the sorting waves
+      int nr = (int)std::min<int64_t>(rows, n_doy - r0);
+      for (;; --nr) {
+        needed_for(r0, nr, need, fresh);
+        if ((int)need.size() <= C || nr == 1) break;
+      }
+      int best = nr;
+      for (int cand = nr; cand >= std::max(1, nr - 2); --cand) {
+        needed_for(r0, cand, need, fresh);
+        if ((int)need.size() <= C && (int)fresh.size() % n_waves == 0) { best = cand; break; }
+      }
+      nr = best;
+      needed_for(r0, nr, need, fresh);
+      // slots: free ones first, then the resident columns whose next use lies farthest ahead (never one needed now)
+      std::vector<char> needed_now(n_doy, 0);
+      for (int c : need) needed_now[c] = 1;
+      std::vector<int> victims;
+      for (int sl = 0; sl < C; ++sl)
+        if (col_in[sl] < 0 || !needed_now[col_in[sl]]) victims.push_back(sl);
+      std::sort(victims.begin(), victims.end(), [&](int a, int b) {
+        const int ua = col_in[a] < 0 ? (1 << 30) + 1 : next_use(col_in[a], r0 + nr);
+        const int ub = col_in[b] < 0 ? (1 << 30) + 1 : next_use(col_in[b], r0 + nr);
+        return ua != ub ? ua > ub : a < b;
+      });
+      soff.push_back((int32_t)sslots.size());
+      const size_t start = list.size();
+      for (size_t i = 0; i < fresh.size(); ++i) {
+        const int sl = victims[i], c = fresh[i];
+        if (col_in[sl] >= 0) slot_of[col_in[sl]] = -1;
+        col_in[sl] = c;
+        slot_of[c] = sl;
+        sslots.push_back(sl);
+        for (int64_t e2 = 0; e2 < S; ++e2) {
+          int64_t t = time_index[int64_t(c) * S + e2];
+          if (t < 0) t += T;  // NumPy negative indexing: -1 is the last time step
+          list.push_back(make_int2((int)t, sl * spad + 1 + (int)e2));
+        }
+      }
+      std::stable_sort(list.begin() + start, list.end(), [](const int2 &a, const int2 &b) { return a.x < b.x; });
+      for (int r = r0; r < r0 + nr; ++r)
+        for (int64_t j = 0; j < W; ++j) cl[size_t(r) * W + j] = (uint16_t)slot_of[cols[int64_t(r) * W + j]];
+      coff.push_back((int)cdoy.size());
+      row0s.push_back(r0);
+      nrows.push_back(nr);
+      ncols.push_back((int)fresh.size());
+      loff.push_back((int)start);
+      llen.push_back((int)(list.size() - start));
+      r0 += nr;
+      ++n_steps;
+    }
+    pl->n_blocks = n_steps;
+  }
+  for (int b = 0; !pl->select_only && b < pl->n_blocks; ++b) {
     const int r0 = b * rows;
     const int nr = (int)std::min<int64_t>(rows, n_doy - r0);
     cols_of_block(r0, nr, set);
@@ -1624,6 +1720,8 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     ncols.push_back((int)set.size());
     loff.push_back((int)start);
     llen.push_back((int)(list.size() - start));
+    soff.push_back((int32_t)sslots.size());
+    for (size_t i = 0; i < set.size(); ++i) sslots.push_back((int32_t)i);
   }
   std::vector<int2> ttop(std::max<size_t>(1, top.size())), tbot(std::max<size_t>(1, bot.size()));
   for (size_t i = 0; i < top.size(); ++i) ttop[i] = make_int2(top[i].rank, top[i].slot);
@@ -1640,6 +1738,9 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   up(pl->blk_list_len, llen.data(), llen.size() * 4);
   up(pl->load_list, list.data(), list.size() * sizeof(int2));
   up(pl->cols_local, cl.data(), cl.size() * 2);
+  if (sslots.empty()) sslots.push_back(0);
+  up(pl->blk_sort_off, soff.data(), soff.size() * 4);
+  up(pl->sort_slots, sslots.data(), sslots.size() * 4);
   up(pl->qparam, qp.data(), qp.size() * sizeof(hdp::QuantileParam));
   up(pl->tgt_top, ttop.data(), ttop.size() * sizeof(int2));
   up(pl->tgt_bot, tbot.data(), tbot.size() * sizeof(int2));
