@@ -7,6 +7,7 @@
 #include <cmath>
 #include <future>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 namespace hdp {
@@ -27,7 +28,34 @@ int set_error(int code, const char *fmt, ...) {
 }
 
 hipStream_t default_stream() { return g_stream; }
-bool device_ready() { return g_device >= 0; }
+// Every extern "C" entry point passes through here first: besides the "hdp_init was called" check it binds the
+// library's device to the CALLING thread (hipSetDevice is per thread; hdp_init only bound the thread that ran it,
+// so a call from another host thread with LOCAL_RANK != 0 would otherwise allocate and launch on device 0).
+bool device_ready() {
+  if (g_device < 0) return false;
+  static thread_local int bound = -1;
+  if (bound != g_device) {
+    if (hipSetDevice(g_device) != hipSuccess) return false;
+    bound = g_device;
+  }
+  return true;
+}
+
+long long env_option(const char *name, long long dflt) {
+  const char *v = getenv(name);
+  if (!v || !*v) return dflt;
+  static std::mutex mu;
+  static std::vector<std::string> seen;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(seen.begin(), seen.end(), name) == seen.end()) {
+      seen.emplace_back(name);
+      fprintf(stderr, "[hdp] environment override %s=%s is in effect (kernel selector for tests and A/B runs; "
+                      "results do not depend on it)\n", name, v);
+    }
+  }
+  return atoll(v);
+}
 
 static hipStream_t pick(void *stream) { return stream ? static_cast<hipStream_t>(stream) : g_stream; }
 

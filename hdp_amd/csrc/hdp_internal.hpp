@@ -22,6 +22,9 @@ constexpr size_t kLdsPerCU = 160 * 1024;
 int set_error(int code, const char *fmt, ...);
 hipStream_t default_stream();
 bool device_ready();
+// Value of an HDP_* selector variable, or `dflt` when it is not set.  Selectors are read when a plan is created,
+// never at launch; the first time one is found set, a notice naming it goes to stderr.
+long long env_option(const char *name, long long dflt);
 
 #define HDP_HIP_TRY(expr)                                                          \
   do {                                                                             \
@@ -44,11 +47,17 @@ struct DevBuf {
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
+  // Invariant: bytes == 0 whenever p == nullptr (a failed allocation leaves the buffer empty, so the
+  // "bytes >= need" guards of the plan-owned scratch buffers re-allocate instead of launching on a null pointer).
   hipError_t alloc(size_t n) {
     release();
-    bytes = n;
     if (n == 0) return hipSuccess;
-    return hipMalloc(&p, n);
+    void *q = nullptr;
+    const hipError_t e = hipMalloc(&q, n);
+    if (e != hipSuccess || q == nullptr) return e == hipSuccess ? hipErrorOutOfMemory : e;
+    p = q;
+    bytes = n;
+    return hipSuccess;
   }
   hipError_t upload(const void *src, size_t n) {
     hipError_t e = alloc(n);
@@ -104,7 +113,16 @@ struct hdp_threshold_plan {
   hdp::DevBuf ninf;         // four floats, -inf
   bool vec = false;         // lpc == 16 and the block columns split into runs (>= 4) of adjacent time steps
   hdp::DevBuf blk_grp_off, grp_col;  // vec: int32 [n_blocks + 1] offsets, first column of every group of four
-  mutable hdp::DevBuf clk;       // HDP_THR_DEBUG=8 phase clocks
+  mutable hdp::DevBuf clk;       // HDP_THR_DEBUG=8 phase clocks (-DHDP_DEBUG_ABLATIONS builds only)
+  // lane-per-column kernel (S <= 100, W <= 16): one lane sorts one column in registers, no cross-lane stage
+  bool lane = false;
+  int32_t lane_n = 0;            // register slots per column: the kernel's template parameter N >= S
+  hdp::DevBuf tixl;              // int32 per block [S][64 * tasks]: byte offset of sample s of local column c
+  hdp::DevBuf blk_tixl_off;      // int32 [n_blocks] first element of each block in tixl
+  // HDP_THR_* selectors (testing and A/B only; every value gives the same results): read ONCE, when the plan is
+  // created, and kept here -- a launch never looks at the environment.  -1 / 0 = not set.
+  int32_t opt_pipe = -1, opt_vec = -1, opt_select = -1, opt_lane = -1;
+  int64_t opt_grid = 0;
 };
 
 struct hdp_metrics_plan {
@@ -120,6 +138,9 @@ struct hdp_metrics_plan {
   mutable hdp::DevBuf rows_scratch;  // (percentile, definition)-per-lane kernels: [4][P][D][batch][Ypitch] int16
   // split path: the streaming exceedance kernel of batch b+1 runs on a second stream beside the
   // VALU-bound state-machine kernel of batch b (created on first use, owned by the plan)
+  // HDP_METRICS_* selectors (testing and A/B only; every value gives the same results), read once at plan creation
+  int32_t opt_general = 0, opt_fused = 0, opt_cells = 1, opt_packed = 1, opt_overlap = 1;
+  int64_t opt_batch = 0;
   mutable hipStream_t aux_stream = nullptr, aux_stream2 = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_exceed[2] = {nullptr, nullptr}, ev_state[2] = {nullptr, nullptr};
   ~hdp_metrics_plan() {

@@ -28,6 +28,12 @@
 
 namespace hdp {
 
+#ifdef HDP_DEBUG_ABLATIONS
+#define HDP_MDBG(md, mask) ((md).debug & (mask))
+#else
+#define HDP_MDBG(md, mask) 0
+#endif
+
 struct MetDev {
   const uint16_t *doy_map;  // [T rounded up to 64]
   const int32_t *defs;      // [D][3]
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
         bits64[q * kRow + (lane & 31)] = brow[int64_t(q) * md.words_pad + w0 + (lane & 31)];
     }
     // ---- stage A: exceedance words, kQB percentiles at a time; lane w of lo/hi = word w ----------
-    for (int q0 = 0; q0 < np && !SPLIT && !(md.debug & 2); q0 += kQB) {
+    for (int q0 = 0; q0 < np && !SPLIT && !HDP_MDBG(md, 2); q0 += kQB) {
       uint32_t lo[kQB], hi[kQB];
       int roff[kQB];  // LDS row of each percentile of the batch (clamped: the tail repeats the last row)
 #pragma unroll
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- stage B: 32-day half-words, run by run ---------------------------------------------------
-    for (int hw = 0; hw < 2 * nw && !(md.debug & 1); ++hw) {
+    for (int hw = 0; hw < 2 * nw && !HDP_MDBG(md, 1); ++hw) {
       const int t0 = w0 * 64 + hw * 32;
       while (si < Y && sb + dmax <= t0) HDP_FINALIZE(true);  // wave-uniform
       const uint32_t word = valid ? bits32[pi * (2 * kRow) + hw] : 0u;
@@ -1502,7 +1508,11 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   md.np_max = std::min(md.P, 63 / md.D + 2);
   md.n_doy_pad = (md.n_doy + 3) & ~3;
   md.dmax = (int)plan->dmax;
+#ifdef HDP_DEBUG_ABLATIONS
   md.debug = getenv("HDP_METRICS_DEBUG") ? atoi(getenv("HDP_METRICS_DEBUG")) : 0;
+#else
+  md.debug = 0;
+#endif
   md.bits_g = nullptr;
   md.out_cells = n_cells;
   md.cell_off = 0;

@@ -39,20 +39,29 @@ struct ThrDev {
   const int2 *tgt_top, *tgt_bot;
   const int32_t *blk_sort_off, *sort_slots;  // one-workgroup-per-cell kernel: LDS column slots a block (re)loads and sorts
   const int32_t *tix, *blk_col_off;  // pipelined kernel: (block column, sample) -> time index
+  const int32_t *tixl, *blk_tixl_off;  // lane-per-column kernel: per block [S][64 * tasks] byte offsets of the samples
   const float *ninf;                 // four -inf words (what a slot without a sample loads)
   const int32_t *blk_grp_off, *grp_col;  // 16-byte gathers: first column of every group of four, per block
   int SL, n_merge;                             // pitch of tix (8 * lanes per column); merging waves
   int select;                                  // one-workgroup-per-cell kernel: rank selection instead of the merge
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
-  // Timing ablations and instrumentation only (HDP_THR_DEBUG, a bit mask; results are wrong under 1, 2, 4):
+  // Timing ablations and instrumentation: compiled in only with -DHDP_DEBUG_ABLATIONS (a release build ignores
+  // HDP_THR_DEBUG and carries none of this code).  Bit mask; results are wrong under 1, 2, 4:
   //   1 no merge, 2 no sort, 4 no sample loads, 8 phase clocks of the one-workgroup-per-cell kernel (forces it),
   //   32 phase clocks of the pipelined kernel (merging wave / first producer), 512 with 32: start-up and step
   //   loop of the merge instead of the producer phases, 64 roles by wave number instead of by SIMD,
   //   4096 print the kernel variant chosen.  The clocks cost about 10 % and serialise on global atomics.
   int debug;
   unsigned long long *clk;  // [8] accumulated s_memtime ticks (debug & 8, debug & 32)
+  long long grid_override;  // HDP_THR_GRID as read at plan creation (0: the occupancy-derived grid)
 };
+
+#ifdef HDP_DEBUG_ABLATIONS
+#define HDP_DBG(pd, mask) ((pd).debug & (mask))
+#else
+#define HDP_DBG(pd, mask) 0
+#endif
 
 constexpr int kThrThreads = 512;  // 8 waves: all of them load and sort, ceil(rows/64) of them merge
 
@@ -482,7 +491,7 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
 #pragma unroll
     for (int j = 0; j < 4 * NG; ++j) clr[j] = (j < pd.W) ? int(cl[j]) : 0;
     unsigned long long tm0 = 0, tm1 = 0;
-    if (pd.debug & 512) tm0 = __builtin_readcyclecounter();
+    if (HDP_DBG(pd, 512)) tm0 = __builtin_readcyclecounter();
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       double hd[4];
@@ -501,7 +510,7 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
     int k = 0;
     int next_rank = nt > 0 ? ldk(&tgt[0]).x : -1;
     double prev = pk_make(worst, 0);
-    if (pd.debug & 512) {
+    if (HDP_DBG(pd, 512)) {
       asm volatile("" ::"v"(m[0]));
       tm1 = __builtin_readcyclecounter();
     }
@@ -537,7 +546,7 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
         next_rank = __builtin_amdgcn_readfirstlane(next_rank);
       }
     }
-    if ((pd.debug & 512) && r == 0) {
+    if (HDP_DBG(pd, 512) && r == 0) {
       asm volatile("" ::"v"(m[0]));
       const unsigned long long tm2 = __builtin_readcyclecounter();
       atomicAdd(&pd.clk[4], tm1 - tm0);
@@ -584,7 +593,120 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
   }
 }
 
-template <int NG>
+
+// ---- the same merge, software-pipelined -----------------------------------------------------------------
+// merge_row issues a step in program order: three LDS reads, wait, 25 vector instructions, two writes -- the wave
+// sits out the LDS round trip and THEN issues everything.  But the next winner needs only two of those instructions:
+// the popped group's new top is max(new head, its old second) and the next winner is max(that, second cached top).
+// So a step here (1) takes the data its reads brought, (2) computes the next winner and ISSUES THE NEXT STEP'S READS,
+// and only then (3) finishes the group insertion, writes the group back and finishes the cached tops, all in the
+// shadow of the reads in flight.  The reads of step k+1 are therefore issued before the write-back of step k: when
+// both steps pop from the same group, the group's heads are taken from registers (three selects), not from the
+// stale strip; any older write is already ahead of the read in the wave's in-order LDS queue.  Same comparisons, same
+// results as merge_row.
+template <bool TOP, int NG>
+__device__ __forceinline__ void merge_row_pl(const ThrDev &pd, const float *colbuf_f, float *hbuf_f, uint32_t *posb,
+                                             const uint16_t *cl, int r, const RowFlags &rf, bool store, double *orow) {
+  static_assert(NG >= 1, "pipelined merge needs the grouped heads");
+  const int *colbuf = reinterpret_cast<const int *>(colbuf_f);
+  const int RP = pd.RP;
+  const int steps = TOP ? pd.steps_top : pd.steps_bot;
+  const int nt = TOP ? pd.nt_top : pd.nt_bot;
+  const int2 *tgt = TOP ? pd.tgt_top : pd.tgt_bot;
+  if (steps == 0) return;
+  const int worst = TOP ? kKeyMin : kKeyMax;
+  auto better = [](double a, double b) { return TOP ? pk_max(a, b) : pk_min(a, b); };
+  auto worse = [](double a, double b) { return TOP ? pk_min(a, b) : pk_max(a, b); };
+  double2 *sa = reinterpret_cast<double2 *>(hbuf_f);
+  double2 *sb = reinterpret_cast<double2 *>(posb);
+  double m[NG];
+  {
+    int clr[4 * NG];
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) clr[j] = (j < pd.W) ? int(cl[j]) : 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      double hd[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 4 * g + i;
+        const int pos = (j < pd.W) ? clr[j] * pd.S_pad + (TOP ? 1 : pd.S) : 0;
+        hd[i] = pk_make((j < pd.W) ? colbuf[pos] : worst, (uint32_t(pos) << 2) | uint32_t(g));
+      }
+      sort_best_first<TOP, 4>(hd);
+      sa[g * RP + r] = make_double2(hd[0], hd[1]);
+      sb[g * RP + r] = make_double2(hd[2], hd[3]);
+      m[g] = hd[0];
+    }
+    sort_best_first<TOP, NG>(m);
+  }
+  int k = 0;
+  int next_rank = nt > 0 ? ldk(&tgt[0]).x : -1;
+  double prev = pk_make(worst, 0);
+
+  // reads of one step, in flight
+  int nk;            // next key of the popped column
+  double2 ha, hb;    // the popped group's strip: (top, 2nd), (3rd, 4th)
+  uint32_t lo_cur;   // low word of the popped head: position << 2 | group
+  int gidx_cur;
+  auto issue = [&](double top) {
+    lo_cur = uint32_t(__double2loint(top));
+    gidx_cur = __mul24(int(lo_cur & 3u), RP) + r;
+    nk = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(colbuf) + (lo_cur & 0x7ffffffcu) + (TOP ? 4 : -4));
+    ha = sa[gidx_cur];
+    hb = sb[gidx_cur];
+  };
+  // the previous step's group after its insertion (registers): what the strip will hold once its write-back lands
+  double b1 = 0.0, b2 = 0.0, b3 = 0.0;
+  int gidx_prev = -1;
+  issue(m[0]);
+  auto do_step = [&]() {
+    prev = m[0];
+    const uint32_t lo = lo_cur;
+    const int gidx = gidx_cur;
+    const bool same = gidx == gidx_prev;
+    const double h1 = same ? b1 : ha.y, h2 = same ? b2 : hb.x, h3 = same ? b3 : hb.y;
+    const double fresh = pk_make(nk, (lo & 0x7fffffffu) + (TOP ? 4u : -4u));
+    const double t0 = better(fresh, h1);  // the group's new top
+    double m0n = t0;
+    if constexpr (NG >= 2) m0n = better(t0, m[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(m0n);  // next step's reads go out before anything else of this step is finished
+    __builtin_amdgcn_sched_barrier(0);
+    // finish the group: (fresh, h1, h2, h3) with h1 >= h2 >= h3 -> sorted best-first
+    const double w1 = worse(fresh, h1);
+    b1 = better(w1, h2);
+    const double w2 = worse(w1, h2);
+    b2 = better(w2, h3);
+    b3 = worse(w2, h3);
+    sa[gidx] = make_double2(t0, b1);
+    sb[gidx] = make_double2(b2, b3);
+    gidx_prev = gidx;
+    // finish the cached tops: (t0, m[1..NG)) -> sorted best-first
+    m[0] = m0n;
+    if constexpr (NG >= 2) {
+      double w = worse(t0, m[1]);
+#pragma unroll
+      for (int i = 1; i + 1 < NG; ++i) {
+        const double nb = better(w, m[i + 1]);
+        w = worse(w, m[i + 1]);
+        m[i] = nb;
+      }
+      m[NG - 1] = w;
+    }
+  };
+  int step = 0;
+  while (true) {
+    const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
+    for (; step < stop; ++step) do_step();
+    if (step >= steps) break;
+    // step == next_rank: m[0] is order statistic `step`, prev the one before it
+    emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, pk_key(m[0]), pk_key(prev), rf, store, orow);
+    next_rank = __builtin_amdgcn_readfirstlane(next_rank);
+  }
+}
+
+template <int NG, bool PIPELINED = false>
 __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf, float *hbuf, uint32_t *posb,
                                            const uint32_t *flags, const uint16_t *cl, int r, bool store,
                                            double *orow) {
@@ -607,8 +729,13 @@ __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf
     }
   }
   if (nan_or >> 31) rf.n_pos = -1;
-  merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
-  merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+  if constexpr (PIPELINED && NG >= 1) {
+    merge_row_pl<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+    merge_row_pl<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+  } else {
+    merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+    merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+  }
 }
 
 // ---- rank selection (many samples per column) ---------------------------------------------------
@@ -771,7 +898,7 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
     const int llen = pd.blk_list_len[b];
 
     unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0;
-    if (pd.debug & 8) t_a = __builtin_readcyclecounter();
+    if (HDP_DBG(pd, 8)) t_a = __builtin_readcyclecounter();
     // 1. sentinels + load
     // `ncols` LDS column slots are (re)loaded and sorted by this block; the others keep the sorted columns of
     // earlier blocks (ring schedule of select-only plans; everywhere else the list is 0 .. ncols-1)
@@ -781,7 +908,7 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
       colbuf[lc * pd.S_pad] = __int_as_float(kKeyMax);          // below every ascending walk
       colbuf[lc * pd.S_pad + pd.S + 1] = __int_as_float(kKeyMin);  // below every descending walk
     }
-    if (!(pd.debug & 4)) {
+    if (!HDP_DBG(pd, 4)) {
       // batches of kLoadBatch independent (list entry -> sample -> LDS) chains per thread: all list
       // reads of a batch are issued before the first sample read, all sample reads before the first
       // LDS write, so a thread keeps kLoadBatch HBM requests in flight instead of one
@@ -799,10 +926,10 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
       }
     }
     __syncthreads();
-    if (pd.debug & 8) t_b = __builtin_readcyclecounter();
+    if (HDP_DBG(pd, 8)) t_b = __builtin_readcyclecounter();
 
     // 2. sort every column once
-    if (pd.debug & 2) {
+    if (HDP_DBG(pd, 2)) {
     } else if (pd.S <= 128 && EPL <= 2) {
       if (pd.S <= 8) sort_block_rows<1>(colbuf, pd.S_pad, pd.S, ncols, flags, wave, nwaves, lane);
       else if (pd.S <= 16) sort_block_rows<2>(colbuf, pd.S_pad, pd.S, ncols, flags, wave, nwaves, lane);
@@ -816,13 +943,13 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
       }
     }
     __syncthreads();
-    if (pd.debug & 8) t_c = __builtin_readcyclecounter();
+    if (HDP_DBG(pd, 8)) t_c = __builtin_readcyclecounter();
 
     // 3. + 4. merge and interpolate, one lane per row; every quantile is stored as soon as its
     //         second order statistic comes out of the merge
     if constexpr (SELECT) {
       const int *colk = reinterpret_cast<const int *>(colbuf);
-      if (pd.debug & 1) {
+      if (HDP_DBG(pd, 1)) {
       } else if (pd.W <= 4) select_rows<4>(pd, colk, flags, row0, nrows, tid, cell, out);
       else if (pd.W <= 8) select_rows<8>(pd, colk, flags, row0, nrows, tid, cell, out);
       else if (pd.W == 15) select_rows<15>(pd, colk, flags, row0, nrows, tid, cell, out);  // the default radius 7
@@ -831,7 +958,7 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
       const int row = row0 + tid;
       const uint16_t *cl = pd.cols_local + size_t(row) * pd.W;
       double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
-      if (!(pd.debug & 1)) {
+      if (!HDP_DBG(pd, 1)) {
         switch (pd.Wp >> 2) {
           case 1: merge_both<1>(pd, colbuf, hbuf, posb, flags, cl, tid, true, orow); break;
           case 2: merge_both<2>(pd, colbuf, hbuf, posb, flags, cl, tid, true, orow); break;
@@ -841,7 +968,7 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
       }
     }
     __syncthreads();
-    if ((pd.debug & 8) && tid == 0) {
+    if (HDP_DBG(pd, 8) && tid == 0) {
       t_d = __builtin_readcyclecounter();
       atomicAdd(&pd.clk[0], t_b - t_a);
       atomicAdd(&pd.clk[1], t_c - t_b);
@@ -910,8 +1037,8 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
   __shared__ int s_simd[nwaves];
   uint32_t hwid;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-  const int my_simd = (pd.debug & 64) ? (wave & 3) : int((hwid >> 4) & 3u);
-  const int tg_par = (pd.debug & 64) ? 0 : int((hwid >> 16) & 1u);
+  const int my_simd = HDP_DBG(pd, 64) ? (wave & 3) : int((hwid >> 4) & 3u);
+  const int tg_par = HDP_DBG(pd, 64) ? 0 : int((hwid >> 16) & 1u);
   if (lane == 0) s_simd[wave] = my_simd;
   __syncthreads();
   int rank = 0;
@@ -958,7 +1085,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
     uint32_t *flags_p = flags0 + int(s & 1) * flags_pitch;        // census of block s (being produced)
     const uint32_t *flags_m = flags0 + int((s + 1) & 1) * flags_pitch;  // census of block s - 1 (being merged)
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;  // debug & 32: phase clocks
-    const bool clocked = (pd.debug & 32) && lane == 0 && (rank == 0 || rank == n_merge);
+    const bool clocked = HDP_DBG(pd, 32) && lane == 0 && (rank == 0 || rank == n_merge);
     if (clocked) c0 = c1 = __builtin_readcyclecounter();
     const int64_t cell_p = first_cell + s * wg_per_blk;
     if (producer) {
@@ -997,7 +1124,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
               const int t = tt[j][k];
-              const float *src = (t >= 0 && !(pd.debug & 4)) ? xc + t : pd.ninf;  // pd.ninf: four -inf words
+              const float *src = (t >= 0 && !HDP_DBG(pd, 4)) ? xc + t : pd.ninf;  // pd.ninf: four -inf words
               float4 v;
               __builtin_memcpy(&v, src, 16);  // global_load_dwordx4, any 4-byte alignment
               hold[j][4 * k + 0] = v.x; hold[j][4 * k + 1] = v.y; hold[j][4 * k + 2] = v.z; hold[j][4 * k + 3] = v.w;
@@ -1053,7 +1180,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
                 hold[j][i] = v;
               }
             }
-            if (!(pd.debug & 2)) sort_group_desc<LPC>(hold[j], l);
+            if (!HDP_DBG(pd, 2)) sort_group_desc<LPC>(hold[j], l);
             if constexpr (LPC >= 2) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor1, 0xf, 0xf, false);
             if constexpr (LPC >= 4) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor2, 0xf, 0xf, false);
             if constexpr (LPC >= 8) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppHalfMirror, 0xf, 0xf, false);
@@ -1075,7 +1202,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
     } else if (s >= 1) {
       // ---- merge block `s - 1` out of the LDS image ----------------------------------------------
       const int64_t cell = first_cell + (s - 1) * wg_per_blk;
-      if (mrow < nrows && !(pd.debug & 1)) {
+      if (mrow < nrows && !HDP_DBG(pd, 1)) {
         const int row = row0 + mrow;
         const uint16_t *cl = cl_lds + mrow * pd.W;
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
@@ -1117,11 +1244,318 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev 
         atomicAdd(&pd.clk[1], c3 - c2);
         atomicAdd(&pd.clk[2], c5 - c3);
         atomicAdd(&pd.clk[3], 1ull);
-      } else if (!(pd.debug & 512)) {  // first producer wave: gather issue, sort (+ load wait), wait for the merge, write
+      } else if (!HDP_DBG(pd, 512)) {  // first producer wave: gather issue, sort (+ load wait), wait for the merge, write
         atomicAdd(&pd.clk[4], c1 - c0);
         atomicAdd(&pd.clk[5], c2 - c1);
         atomicAdd(&pd.clk[6], c3 - c2);
         atomicAdd(&pd.clk[7], c4 - c3);
+      }
+    }
+  }
+}
+
+
+// ---- lane-per-column producers (S <= 104): the column sort as a register network -----------------------
+// The 16-lane-row sorter above spends 10 of its 28 stages crossing lanes (a v_mov_dpp + v_med3 pair per key) and
+// pads every column to 128 slots.  Here ONE LANE owns one day-of-year column: its S samples sit in N >= S registers
+// and are sorted by Batcher's merge exchange (Knuth 5.2.2 M) for exactly N keys, fully unrolled -- compare-exchanges
+// are v_max + v_min between two registers, nothing crosses lanes, no padding to a power of two (N = 100: 1077
+// compare-exchanges per 64 columns against 4 x 450 instructions per 4 columns before: 3.3x fewer vector
+// instructions for the sort).  Loads are coalesced without any transposition: the samples of one year of 64
+// adjacent columns are 64 adjacent time steps.  The merging waves, the LDS image and the emission are the ones of
+// thresholds_pipe_kernel; results are bit-identical (tests/test_thresholds_kernels_gpu.py).
+constexpr int ilog2_ceil(int n) {
+  int t = 0;
+  while ((1 << t) < n) ++t;
+  return t;
+}
+// compare-exchange of two order-preserving int keys, larger to `a`.  asm volatile: the statements keep their program
+// order, so the N keys plus one temporary are all that is ever live -- left to itself the scheduler stretches the
+// live ranges of a 1000-comparator network until it spills (N = 100: 256 VGPRs and 417 spills, measured).
+__device__ __forceinline__ void ce_key(int &a, int &b) {
+  int hi;
+  asm volatile("v_max_i32 %0, %1, %2\n\tv_min_i32 %1, %1, %2" : "=&v"(hi), "+v"(b) : "v"(a));
+  a = hi;
+}
+// The passes (p, r, d) of merge exchange for N keys, as compile-time constants: pass k compares v[i] with v[i + d]
+// for every i with (i & p) == r.  Written as a recursion over the pass number so that every index is a constant
+// after inlining (a `break` inside an unrolled loop left run-time indices, i.e. the keys in scratch memory).
+struct LanePass {
+  int p, r, d;
+};
+template <int N>
+struct LaneNet {
+  static constexpr int t = ilog2_ceil(N);
+  static constexpr int count() {
+    int c = 0;
+    for (int pi = t - 1; pi >= 0; --pi) {
+      const int p = 1 << pi;
+      int q = 1 << (t - 1);
+      for (;;) {
+        ++c;
+        if (q == p) break;
+        q >>= 1;
+      }
+    }
+    return c;
+  }
+  static constexpr LanePass pass(int k) {
+    int c = 0;
+    for (int pi = t - 1; pi >= 0; --pi) {
+      const int p = 1 << pi;
+      int q = 1 << (t - 1), r = 0, d = p;
+      for (;;) {
+        if (c == k) return LanePass{p, r, d};
+        ++c;
+        if (q == p) break;
+        d = q - p;
+        q >>= 1;
+        r = p;
+      }
+    }
+    return LanePass{0, 0, 0};
+  }
+};
+template <int N, int K = 0>
+__device__ __forceinline__ void sort_lane_desc(int (&v)[N]) {  // larger key to the lower index
+  if constexpr (N > 1 && K < LaneNet<N>::count()) {
+    constexpr LanePass ps = LaneNet<N>::pass(K);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i + ps.d < N && (i & ps.p) == ps.r) ce_key(v[i], v[i + ps.d]);
+    sort_lane_desc<N, K + 1>(v);
+  }
+}
+
+// global_load_dword with a wave-uniform base (SGPR pair) and a 32-bit byte offset per lane: no 64-bit address
+// arithmetic in vector registers, and the result may land in the register that held the offset.  The caller
+// waits (s_waitcnt vmcnt(0)) before it uses the value: the compiler does not know this is a load.
+__device__ __forceinline__ int ld_saddr(const void *sbase, uint32_t voff) {
+  int r;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+  return r;
+}
+// the same, overwriting the offset register with the loaded value
+__device__ __forceinline__ void ld_saddr_inplace(const void *sbase, int &reg) {
+  asm volatile("global_load_dword %0, %0, %1" : "+v"(reg) : "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// To the compiler an asm load has produced its value when the statement ends, so ordinary code that reads the
+// register may be scheduled ABOVE the s_waitcnt (it was: the census ran on the byte offsets).  An empty volatile asm
+// that "rewrites" the register after the wait makes every later use depend on a statement that stays below it.
+__device__ __forceinline__ void landed(int &reg) { asm volatile("" : "+v"(reg)); }
+
+// slots below this index hold a sample for every S the N-slot kernel is chosen for (S > the next smaller N)
+constexpr int lane_first_pad_slot(int N) {
+  constexpr int kN[] = {0, 8, 16, 24, 32, 48, 64, 80, 100};
+  int prev = 0;
+  for (int n : kN)
+    if (n < N) prev = n;
+  return prev;
+}
+
+// tasks (64 columns each) one producer wave sorts and holds per block
+template <int N>
+constexpr int lane_tasks_per_wave() { return N >= 64 ? 1 : (N >= 32 ? 2 : 4); }
+
+template <int N, int NG>
+__global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev pd, const float *__restrict__ x,
+                                                                      int64_t n_cells, double *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = int(blockDim.x) >> 6;  // merging waves + as many producers as the block's tasks need (<= 8)
+  constexpr int TPW = lane_tasks_per_wave<N>();
+
+  size_t off = 0;
+  float *colbuf = reinterpret_cast<float *>(smem + off);
+  off += (size_t(pd.ncols_max) * pd.S_pad * 4 + 15) & ~size_t(15);
+  uint32_t *flags0 = reinterpret_cast<uint32_t *>(smem + off);  // census words, double-buffered by block parity
+  const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
+  off += 2 * size_t(flags_pitch) * 4;
+  float *hbuf = reinterpret_cast<float *>(smem + off);
+  off += size_t(pd.Wp) * pd.RP * 4;
+  uint32_t *posb = reinterpret_cast<uint32_t *>(smem + off);
+  off += size_t(pd.Wp) * pd.RP * 4;
+  uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][W] local columns of this block's windows
+
+  const int nb = pd.n_blocks;
+  const int blk = int(blockIdx.x) % nb;
+  const int64_t wg_per_blk = gridDim.x / nb;  // the host launches a multiple of n_blocks workgroups
+  const int64_t first_cell = int64_t(blockIdx.x) / nb;
+  const int64_t n_items = first_cell < n_cells ? (n_cells - first_cell + wg_per_blk - 1) / wg_per_blk : 0;
+  const int row0 = pd.blk_row0[blk];
+  const int nrows = pd.blk_nrows[blk];
+  const int ncols = pd.blk_ncols[blk];
+  const int n_tasks = (ncols + 63) >> 6;
+  const uint32_t pitch4 = uint32_t(n_tasks) * 256u;    // bytes per row of the offset table
+  const int32_t *tl = pd.tixl + pd.blk_tixl_off[blk];  // [N][64 * tasks] byte offsets of (sample, local column)
+  for (int i = tid; i < nrows * pd.W; i += int(blockDim.x)) cl_lds[i] = pd.cols_local[size_t(row0) * pd.W + i];
+
+  // Roles by SIMD, as in thresholds_pipe_kernel: one merging wave per SIMD first.
+  const int n_merge = pd.n_merge;
+  const int n_prod = nwaves - n_merge;
+  __shared__ int s_simd[kThrThreads / 64];
+  uint32_t hwid;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+  const int my_simd = int((hwid >> 4) & 3u);
+  const int tg_par = int((hwid >> 16) & 1u);
+  if (lane == 0) s_simd[wave] = my_simd;
+  __syncthreads();
+  int rank = 0;
+  {
+    int occ_me = 0;
+    for (int w = 0; w < wave; ++w) occ_me += (s_simd[w] == my_simd);
+    const int key_me = (occ_me * 4 + ((my_simd - 2 * tg_par) & 3)) * nwaves + wave;
+    for (int w = 0; w < nwaves; ++w) {
+      const int sw = s_simd[w];
+      int occ = 0;
+      for (int u = 0; u < w; ++u) occ += (s_simd[u] == sw);
+      const int key = (occ * 4 + ((sw - 2 * tg_par) & 3)) * nwaves + w;
+      rank += (key < key_me);
+    }
+  }
+  rank = __builtin_amdgcn_readfirstlane(rank);
+  const bool producer = rank >= n_merge;  // wave-uniform
+  if (producer) __builtin_amdgcn_s_setprio(0);
+  else __builtin_amdgcn_s_setprio(3);
+  const int pw = rank - n_merge;      // producer index
+  const int mrow = rank * 64 + lane;  // merging waves: row of the block this lane merges
+
+  // Two loops, one per role, with the same two barriers per item ("image free / keys sorted", "image written"):
+  // s_barrier counts wave arrivals, so waves may reach it from different code.  Written as one loop, the sorted keys
+  // (up to 100 registers) were live across the merging waves' code as well and the kernel spilled.
+  if (producer) {
+    for (int64_t s = 0; s <= n_items; ++s) {
+      int v[TPW][N];  // sorted keys of this wave's tasks
+      uint32_t *flags_p = flags0 + int(s & 1) * flags_pitch;  // census of block s (double-buffered by parity)
+      unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+      const bool clocked = HDP_DBG(pd, 32) && lane == 0 && pw == 0;
+      if (clocked) c0 = __builtin_readcyclecounter();
+      // S as a value made inside the loop: everything derived from it (which slots are padding, where they are
+      // written) is then recomputed per item with scalar instructions instead of being hoisted into registers
+      int S_rt = pd.S;
+      asm volatile("" : "+s"(S_rt));
+      if (s < n_items) {
+        const int64_t cell_p = first_cell + s * wg_per_blk;
+        const char *xc = reinterpret_cast<const char *>(x + cell_p * int64_t(pd.T));
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+          const int task = pw + k * n_prod;  // wave-uniform
+          if (task < n_tasks) {
+            const int lc = task * 64 + lane;
+            const uint32_t lane_b = uint32_t(lc) * 4u;
+            // byte offsets first (coalesced, L2-resident table), then the samples: lanes = adjacent columns =
+            // adjacent time steps, so a load instruction fetches 256 contiguous bytes on a regular calendar.
+            // The table has N rows: rows past S repeat row S - 1 and are overwritten with the sentinel key below.
+            uint32_t toff = lane_b;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+              v[k][i] = ld_saddr(tl, toff);
+              toff += pitch4;
+              asm volatile("" : "+v"(toff));  // one running offset: the N row offsets are loop invariants the compiler
+                                               // would otherwise keep in N registers across the whole item loop
+            }
+            wait_vm0();
+#pragma unroll
+            for (int i = 0; i < N; ++i) ld_saddr_inplace(xc, v[k][i]);
+            wait_vm0();
+#pragma unroll
+            for (int i = 0; i < N; ++i) landed(v[k][i]);
+            if (clocked && k == 0) c1 = __builtin_readcyclecounter();
+            // census of NaN / +-inf (numba's special cases), only when one is present in the wave
+            // (exponent all ones <=> bits << 1 >= 0xff000000: one v_max3_u32 per two samples)
+            uint32_t emax = 0;
+#pragma unroll
+            for (int i = 0; i + 1 < N; i += 2) {
+              const uint32_t a = uint32_t(v[k][i]), b = uint32_t(v[k][i + 1]);
+              emax = max(emax, max(a + a, b + b));
+            }
+            if (N & 1) emax = max(emax, uint32_t(v[k][N - 1]) * 2u);
+            // (slots past S hold a copy of the last sample here)
+            const bool special = emax >= 0xff000000u;
+            uint32_t cnt = 0;  // nan << 20 | +inf << 10 | -inf
+            if (__ballot(special) != 0) {
+#pragma unroll
+              for (int i = 0; i < N; ++i) {
+                const bool real = i < lane_first_pad_slot(N) || i < S_rt;
+                float a = __int_as_float(v[k][i]);
+                if (real && a != a) { cnt += 1u << 20; a = 0.0f; }
+                if (real && a == INFINITY) cnt += 1u << 10;
+                if (real && a == -INFINITY) cnt += 1u;
+                v[k][i] = __float_as_int(a);
+              }
+            }
+            if (lc < ncols)
+              flags_p[lc] = ((cnt >> 20) ? 0x80000000u : 0u) | (((cnt >> 10) & 0x3ffu) << 15) | (cnt & 0x3ffu);
+            // order-preserving keys (what the LDS image holds); slots past S get the trailing sentinel's key and
+            // sort to the tail (wave-uniform select)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+              const int key = f32_key(__int_as_float(v[k][i]));
+              v[k][i] = (i >= lane_first_pad_slot(N) && i >= S_rt) ? kKeyMin : key;
+            }
+            sort_lane_desc<N>(v[k]);
+          }
+        }
+      }
+      if (clocked) c2 = __builtin_readcyclecounter();
+      __syncthreads();  // image free (merge s-1 done), keys of block s sorted
+      if (clocked) c3 = __builtin_readcyclecounter();
+      if (s < n_items) {
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+          const int task = pw + k * n_prod;
+          const int lc = task * 64 + lane;
+          if (task < n_tasks && lc < ncols) {
+            // lane stride S_pad (odd) words: a store instruction hits 64 different banks
+            float *col = colbuf + lc * pd.S_pad + 1;
+            // branch-free: slots past the column's last sample all land on its trailing sentinel
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+              // slots below the first possible padding slot always hold a sample: constant LDS offsets (a run-time
+              // min() on every slot gave N loop-invariant addresses, hoisted into N registers)
+              if (i < lane_first_pad_slot(N)) col[i] = __int_as_float(v[k][i]);
+              else col[min(i, S_rt)] = __int_as_float(v[k][i]);
+            }
+            col[-1] = __int_as_float(kKeyMax);    // below every ascending walk
+            col[S_rt] = __int_as_float(kKeyMin);  // below every descending walk
+          }
+        }
+      }
+      if (clocked) c4 = __builtin_readcyclecounter();
+      __syncthreads();  // image of block s ready
+      if (clocked) {  // first producer wave: loads, census + sort, wait for the merge, image write
+        atomicAdd(&pd.clk[4], c1 - c0);
+        atomicAdd(&pd.clk[5], c2 - c1);
+        atomicAdd(&pd.clk[6], c3 - c2);
+        atomicAdd(&pd.clk[7], c4 - c3);
+      }
+    }
+  } else {
+    for (int64_t s = 0; s <= n_items; ++s) {
+      const uint32_t *flags_m = flags0 + int((s + 1) & 1) * flags_pitch;  // census of block s - 1
+      unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      const bool clocked = HDP_DBG(pd, 32) && lane == 0 && rank == 0;
+      if (clocked) c0 = __builtin_readcyclecounter();
+      if (s >= 1 && mrow < nrows) {
+        const int64_t cell = first_cell + (s - 1) * wg_per_blk;
+        const int row = row0 + mrow;
+        const uint16_t *cl = cl_lds + mrow * pd.W;
+        double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
+        merge_both<NG, true>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow);
+      }
+      if (clocked) c1 = __builtin_readcyclecounter();
+      __syncthreads();  // merge of block s - 1 done: image free
+      if (clocked) c2 = __builtin_readcyclecounter();
+      __syncthreads();  // image of block s ready
+      if (clocked) {  // first merging wave: merge, wait for the producers, wait for the image
+        c3 = __builtin_readcyclecounter();
+        atomicAdd(&pd.clk[0], c1 - c0);
+        atomicAdd(&pd.clk[1], c2 - c1);
+        atomicAdd(&pd.clk[2], c3 - c2);
+        atomicAdd(&pd.clk[3], 1ull);
       }
     }
   }
@@ -1255,12 +1689,63 @@ static int launch_thr_pipe(const ThrDev &pd, size_t lds, const float *x, int64_t
   // a multiple of n_blocks: workgroup w works on block w % n_blocks for cells w / n_blocks + k * (grid / n_blocks)
   const int64_t nb = pd.n_blocks;
   int64_t resident = int64_t(per_cu) * n_cu;
-  if (const char *env = getenv("HDP_THR_GRID")) resident = std::max<int64_t>(1, atoll(env));
+  if (pd.grid_override > 0) resident = pd.grid_override;
   int64_t grid = std::max<int64_t>(1, std::min<int64_t>(resident / nb, n_cells)) * nb;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThrThreads), lds, stream, pd, x, n_cells, out);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
 }
+
+// persistent grid shared by the pipelined and the lane-per-column kernel: as many workgroups as the device keeps
+// resident, a multiple of n_blocks (workgroup w works on block w % n_blocks for cells w / n_blocks + k * (grid / n_blocks))
+template <class Kern>
+static int launch_thr_persistent(Kern kern, const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
+                                 int64_t grid_override, int threads, hipStream_t stream) {
+  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    HDP_HIP_TRY(hipGetDevice(&dev));
+    HDP_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  int per_cu = 0;
+  HDP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern),
+                                                           threads, lds));
+  if (per_cu < 1) per_cu = 1;
+  const int64_t nb = pd.n_blocks;
+  int64_t resident = int64_t(per_cu) * n_cu;
+  if (grid_override > 0) resident = grid_override;
+  int64_t grid = std::max<int64_t>(1, std::min<int64_t>(resident / nb, n_cells)) * nb;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, stream, pd, x, n_cells, out);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+template <int N>
+static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
+                           int64_t grid_override, hipStream_t stream) {
+  // merging waves + the producers the widest block needs: at S = 100 that is 2 + 3 waves, and two such workgroups
+  // per CU leave every wave the 160 registers a 100-key column takes
+  const int tpw = lane_tasks_per_wave<N>();
+  const int n_tasks = (pd.ncols_max + 63) / 64;
+  const int threads = std::min<int>(kThrThreads, 64 * (pd.n_merge + (n_tasks + tpw - 1) / tpw));
+  switch (pd.Wp >> 2) {
+    case 1: return launch_thr_persistent(thresholds_lane_kernel<N, 1>, pd, lds, x, n_cells, out, grid_override, threads, stream);
+    case 2: return launch_thr_persistent(thresholds_lane_kernel<N, 2>, pd, lds, x, n_cells, out, grid_override, threads, stream);
+    case 4: return launch_thr_persistent(thresholds_lane_kernel<N, 4>, pd, lds, x, n_cells, out, grid_override, threads, stream);
+    default: return set_error(HDP_EUNSUP, "lane-per-column kernel: unsupported window width");
+  }
+}
+
+// register slots per column the lane-per-column kernel is instantiated for (0: S too large)
+static int lane_slots_for(int64_t S) {
+  static const int kN[] = {8, 16, 24, 32, 48, 64, 80, 100};
+  for (int n : kN)
+    if (S <= n) return n;
+  return 0;
+}
+static int lane_tasks_per_wave_rt(int N) { return N >= 64 ? 1 : (N >= 32 ? 2 : 4); }
 
 // run-time (lanes per column, 16-byte gathers, head groups) -> kernel instantiation
 template <int LPC, bool VEC>
@@ -1274,21 +1759,22 @@ static int launch_thr_pipe_ng(const ThrDev &pd, size_t lds, const float *x, int6
   }
 }
 
-// Which kernel a launch of this plan runs: the plan's choice, overridden by the environment switches
-// (read at every launch so one process can compare the variants on the same input).
+// Which kernel a launch of this plan runs: the plan's choice under the HDP_THR_* selectors that were in the
+// environment WHEN THE PLAN WAS CREATED (tests create one plan per variant to compare them on the same input).
 struct ThrVariant {
-  bool pipe, vec, select;
+  bool lane, pipe, vec, select;
 };
 static ThrVariant thr_variant(const hdp_threshold_plan *plan, int debug) {
   ThrVariant v;
-  const char *pipe_env = getenv("HDP_THR_PIPE");
-  v.pipe = plan->pipe && !(pipe_env && atoi(pipe_env) == 0) && !(debug & 8);
-  const char *vec_env = getenv("HDP_THR_VEC");
-  v.vec = v.pipe && plan->lpc == 16 && plan->vec && !(vec_env && atoi(vec_env) == 0);
+  const bool pipe_allowed = plan->opt_pipe != 0 && !(debug & 8);
+  v.lane = plan->lane && pipe_allowed && plan->opt_lane != 0;
+  v.pipe = !v.lane && plan->pipe && pipe_allowed;
+  v.vec = v.pipe && plan->lpc == 16 && plan->vec && plan->opt_vec != 0;
   // rank selection pays once the merge is deep (a lane per (row, rank) instead of a lane per row);
   // HDP_THR_SELECT=0/1 forces the choice for tests
-  v.select = !v.pipe && (plan->W <= 16) && (plan->steps_top + plan->steps_bot >= 512);
-  if (const char *env = getenv("HDP_THR_SELECT")) v.select = !v.pipe && (plan->W <= 16) && atoi(env) != 0;
+  const bool wg_per_cell = !v.lane && !v.pipe;
+  v.select = wg_per_cell && (plan->W <= 16) && (plan->steps_top + plan->steps_bot >= 512);
+  if (plan->opt_select >= 0) v.select = wg_per_cell && (plan->W <= 16) && plan->opt_select != 0;
   if (plan->select_only) v.select = true;  // the plan's LDS image has no room for merge heads
   return v;
 }
@@ -1296,9 +1782,13 @@ static ThrVariant thr_variant(const hdp_threshold_plan *plan, int debug) {
 extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *plan) {
   static thread_local char buf[256];
   if (!plan) return "";
-  const int debug = getenv("HDP_THR_DEBUG") ? atoi(getenv("HDP_THR_DEBUG")) : 0;
-  const ThrVariant v = thr_variant(plan, debug);
-  if (v.pipe)
+  const ThrVariant v = thr_variant(plan, 0);
+  if (v.lane)
+    snprintf(buf, sizeof buf,
+             "thresholds_lane_kernel<N=%d,NG=%d> (one lane per column: register merge-exchange sort; %d merging waves; "
+             "%d rows x %d blocks, %zu B LDS)",
+             plan->lane_n, plan->Wp >> 2, plan->n_merge, plan->rows_per_block, plan->n_blocks, plan->lds_bytes);
+  else if (v.pipe)
     snprintf(buf, sizeof buf,
              "thresholds_pipe_kernel<LPC=%d,%s,NG=%d> (register sort producers + %d merging waves; %d rows x %d blocks, "
              "%zu B LDS)",
@@ -1354,7 +1844,14 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.grp_col = plan->grp_col.as<int32_t>();
   pd.SL = 8 * plan->lpc;
   pd.n_merge = plan->n_merge;
+  pd.tixl = plan->tixl.as<int32_t>();
+  pd.blk_tixl_off = plan->blk_tixl_off.as<int32_t>();
+  pd.grid_override = plan->opt_grid;
+#ifdef HDP_DEBUG_ABLATIONS
   pd.debug = getenv("HDP_THR_DEBUG") ? atoi(getenv("HDP_THR_DEBUG")) : 0;
+#else
+  pd.debug = 0;
+#endif
   pd.clk = nullptr;
   if (pd.debug & (8 | 32)) {
     if (plan->clk.bytes == 0) {
@@ -1365,6 +1862,19 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   }
   const ThrVariant var = thr_variant(plan, pd.debug);
   pd.select = var.select;
+  if (var.lane) {
+    switch (plan->lane_n) {
+      case 8: return launch_thr_lane<8>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 16: return launch_thr_lane<16>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 24: return launch_thr_lane<24>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 32: return launch_thr_lane<32>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 48: return launch_thr_lane<48>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 64: return launch_thr_lane<64>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 80: return launch_thr_lane<80>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 100: return launch_thr_lane<100>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      default: return set_error(HDP_EUNSUP, "lane-per-column kernel: no instantiation for %d slots", plan->lane_n);
+    }
+  }
   if (var.pipe) {
     switch (plan->lpc) {
       case 1: return launch_thr_pipe_ng<1, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
@@ -1372,7 +1882,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
       case 4: return launch_thr_pipe_ng<4, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       case 8: return launch_thr_pipe_ng<8, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
       default: {
-        if (pd.debug & 4096) fprintf(stderr, "[hdp thresholds] %s\n", hdp_threshold_plan_describe(plan));
+        if (HDP_DBG(pd, 4096)) fprintf(stderr, "[hdp thresholds] %s\n", hdp_threshold_plan_describe(plan));
         if (var.vec)
           return launch_thr_pipe_ng<16, true>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
         return launch_thr_pipe_ng<16, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
@@ -1440,6 +1950,12 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
 
   auto *pl = new hdp_threshold_plan();
   pl->n_doy = n_doy; pl->S = S; pl->W = W; pl->P = P; pl->T = T;
+  pl->opt_pipe = (int32_t)hdp::env_option("HDP_THR_PIPE", -1);
+  pl->opt_vec = (int32_t)hdp::env_option("HDP_THR_VEC", -1);
+  pl->opt_select = (int32_t)hdp::env_option("HDP_THR_SELECT", -1);
+  pl->opt_lane = (int32_t)hdp::env_option("HDP_THR_LANE", -1);
+  pl->opt_grid = hdp::env_option("HDP_THR_GRID", 0);
+  const int opt_rows = (int)hdp::env_option("HDP_THR_ROWS", 0);
   pl->n = W * S;
   pl->Wp = int((W + 3) & ~int64_t(3));
   int spad = int(S) + 2;
@@ -1488,10 +2004,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   // choose rows per block against the LDS budget
   // Plans that can only ever run the rank selection (more than 128 samples per column, deep ranks, W <= 16, and
   // HDP_THR_SELECT not 0 when the plan is made) need no merge heads in LDS: two more columns per block at S = 1000.
-  {
-    const char *env = getenv("HDP_THR_SELECT");
-    pl->select_only = S > 128 && W <= 16 && (pl->steps_top + pl->steps_bot >= 512) && !(env && atoi(env) == 0);
-  }
+  pl->select_only = S > 128 && W <= 16 && (pl->steps_top + pl->steps_bot >= 512) && pl->opt_select != 0;
   auto lds_for = [&](int rows, int ncols) -> size_t {
     const int RP = (rows + 63) & ~63;
     size_t b = (size_t(ncols) * spad * 4 + 15) & ~size_t(15);
@@ -1543,8 +2056,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     return worst;
   };
   const size_t kMaxLds = 160 * 1024 - 1024;
-  int rows = 0;
-  if (const char *env = getenv("HDP_THR_ROWS")) rows = atoi(env);
+  int rows = opt_rows;
   if (rows <= 0) {
     // largest row count whose worst block fits `cap` bytes of LDS
     auto fit = [&](size_t cap) -> int {
@@ -1563,7 +2075,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
       rows = int((n_doy + nb - 1) / nb);  // balance the blocks
     }
   }
-  const bool rows_forced = getenv("HDP_THR_ROWS") != nullptr;
+  const bool rows_forced = opt_rows > 0;
   rows = (int)std::min<int64_t>(rows, std::min<int64_t>(n_doy, hdp::kThrThreads));
   int cm = 0;
   if (rows <= 0 || max_lds_for_rows(rows, &cm) > kMaxLds) {
@@ -1585,8 +2097,32 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     const int kc = 64 / lpc, ng = (ncols_max + kc - 1) / kc;
     return (ng + np - 1) / np <= hdp::kHold;
   };
+  // lane-per-column kernel: every producer wave sorts (and holds) up to lane_tasks_per_wave tasks of 64 columns
+  const int ngw = pl->Wp >> 2;  // head groups of four: the merge is instantiated for 1, 2 and 4
+  const int lane_n = (ngw == 1 || ngw == 2 || ngw == 4) ? hdp::lane_slots_for(S) : 0;
+  auto lane_ok = [&](int r, int ncols_max) -> bool {
+    if (!lane_n) return false;
+    const int nm = (r + 63) / 64, np = hdp::kThrThreads / 64 - nm;
+    if (np < 1) return false;
+    return (ncols_max + 63) / 64 <= np * hdp::lane_tasks_per_wave_rt(lane_n);
+  };
+  bool lane = lane_ok(rows, cm);
   bool pipe = pipe_ok(rows, cm);
-  if (lpc && !pipe && !rows_forced) {
+  if (lane_n && !lane && !rows_forced) {
+    for (int r = rows - 1; r >= std::max(1, rows / 2); --r) {
+      const int nb = int((n_doy + r - 1) / r);
+      const int rb = int((n_doy + nb - 1) / nb);
+      int c2 = 0;
+      if (max_lds_for_rows(rb, &c2) <= kMaxLds && lane_ok(rb, c2)) {
+        rows = rb; cm = c2; lane = true;
+        pipe = pipe_ok(rows, cm);
+        break;
+      }
+    }
+  }
+  pl->lane = lane;
+  pl->lane_n = lane_n;
+  if (lpc && !pipe && !lane && !rows_forced) {
     for (int r = rows - 1; r >= std::max(1, rows / 2); --r) {
       const int nb = int((n_doy + r - 1) / r);
       const int rb = int((n_doy + nb - 1) / nb);
@@ -1778,7 +2314,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
         if (!adjacent) {  // run [run0, c)
           const int len = c - run0;
           if (len < 4) {
-            if (getenv("HDP_THR_DEBUG")) fprintf(stderr, "[hdp thresholds] vec off: block %d run [%d,%d)\n", b, run0, c);
             vec = false;
             break;
           }
@@ -1788,7 +2323,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
       }
       const int ng = int(gcol.size()) - goff.back();
       if (vec && (ng + n_prod - 1) / n_prod > hdp::kHold) {
-        if (getenv("HDP_THR_DEBUG")) fprintf(stderr, "[hdp thresholds] vec off: block %d has %d groups for %d producers\n", b, ng, n_prod);
         vec = false;
       }
     }
@@ -1798,6 +2332,27 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
       up(pl->grp_col, gcol.data(), gcol.size() * 4);
     }
     pl->vec = vec;
+  }
+  if (pl->lane) {
+    // per block [N][64 * tasks]: BYTE offset of sample s of local column c (pad lanes repeat the last column)
+    std::vector<int32_t> tl, tloff;
+    for (int b = 0; b < pl->n_blocks; ++b) {
+      const int nc = ncols[b], pitch = ((nc + 63) / 64) * 64;
+      tloff.push_back((int32_t)tl.size());
+      const size_t base = tl.size();
+      tl.resize(base + size_t(lane_n) * pitch, 0);
+      for (int c = 0; c < pitch; ++c) {
+        const int doy = cdoy[size_t(coff[b]) + std::min(c, nc - 1)];
+        for (int64_t e2 = 0; e2 < lane_n; ++e2) {  // rows past S repeat the last sample (the kernel discards them)
+          int64_t t = time_index[int64_t(doy) * S + std::min<int64_t>(e2, S - 1)];
+          if (t < 0) t += T;  // NumPy negative indexing: -1 is the last time step
+          tl[base + size_t(e2) * pitch + c] = (int32_t)(t * 4);
+        }
+      }
+    }
+    if (T >= (int64_t(1) << 29)) pl->lane = false;  // byte offsets must fit 31 bits
+    up(pl->tixl, tl.data(), tl.size() * 4);
+    up(pl->blk_tixl_off, tloff.data(), tloff.size() * 4);
   }
   if (e != hipSuccess) {
     delete pl;

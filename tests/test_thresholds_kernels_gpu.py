@@ -1,12 +1,15 @@
 """Every thresholds kernel variant against the C oracle and against each other (bit-exact).
 
-The library picks a kernel from the plan: the pipelined kernel (wave-specialised, register sort with
+The library picks a kernel from the plan: the lane-per-column kernel (up to 100 samples per column and 16 window
+columns: one lane sorts one column in registers by a merge-exchange network; HDP_THR_LANE=0 turns it off), the
+pipelined kernel (wave-specialised, register sort with
 8 * LPC keys per column, LPC in {1, 2, 4, 8, 16}; 16-byte gathers when the calendar is regular; merge
 templated on the number of head groups NG in {1, 2, 4}, generic rescan for wider windows) or the
 one-workgroup-per-cell kernel (HDP_THR_PIPE=0, also the path for more than 128 samples per column), which
 finishes a block either with the merge or, when the requested ranks lie deep (HDP_THR_SELECT), with a rank
 selection per (row, requested rank).
-The environment switches are read at launch, so one process can run them all on the same input.
+The environment switches are read when a plan is created (core.compute_percentiles makes one per call), so one
+process can run them all on the same input.
 """
 import zlib
 
@@ -68,15 +71,16 @@ def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
         want = c_oracle.thresholds(x, win, q)
 
     def run(**env):
-        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT"):
+        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         return core.compute_percentiles(x, ti, cols, q)
 
-    got = run()
+    got = run()                                        # lane-per-column kernel where the plan allows it
     assert same_f64(got, want)
-    assert same_f64(run(HDP_THR_VEC="0"), want)       # pipelined kernel, one dword per (column, sample)
+    assert same_f64(run(HDP_THR_LANE="0"), want)      # pipelined kernel (16-byte gathers on regular calendars)
+    assert same_f64(run(HDP_THR_LANE="0", HDP_THR_VEC="0"), want)   # pipelined kernel, one dword per (column, sample)
     assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="0"), want)   # one workgroup per cell, merge
     assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="1"), want)   # same, rank selection per (row, rank)
 
@@ -130,9 +134,9 @@ def test_random_calendars_windows_and_quantiles(seed, monkeypatch):
     win = cal.expand_window_table(ti, cols)
     with np.errstate(invalid="ignore"):
         want = c_oracle.thresholds(x, win, q)
-    for env in ({}, {"HDP_THR_VEC": "0"}, {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "0"},
-                {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "1"}):
-        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT"):
+    for env in ({}, {"HDP_THR_LANE": "0"}, {"HDP_THR_LANE": "0", "HDP_THR_VEC": "0"},
+                {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "0"}, {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "1"}):
+        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
