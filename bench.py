@@ -1,21 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- grid-cell-days/sec of compute_thresholds + compute_group_metrics on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5|tiny] [--layout cm|tm]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic input already resident in
-HBM: the thresholds kernel over the baseline series and the metrics kernel over the measure
-series of every grid cell a rank owns.  Grid cells are independent, so ranks shard them with
-no data-path collective (weak scaling: every rank processes the full per-GPU workload); the
-RCCL all-gather that reassembles the metrics Dataset is exercised and reported separately
-(`allgather`), never inside `value`.
+One "step" = one pass of the hot path over the synthetic grid the config names: the thresholds kernel over
+the baseline series and the metrics kernel over the measure series of every grid cell a rank owns.
 
-torch is used only as plumbing here (process group, barrier, the all-gather, device buffers
-whose raw pointers go to the C ABI).  The kernels are launched on torch's current stream and
-timed there with HIP events (hdp_event_*), which is what `roofline.achieved` is computed from.
+Multi-GPU (BASELINE.json configs[3], the reference's only parallelism: threshold.py:161-169, metric.py:444-452):
+ONE grid is sharded over the ranks by contiguous cell ranges (hdp_amd.dist.shard_bounds) -- strong scaling, no
+data-path collective; `value` = cell-days of the whole grid / max-over-ranks step time.  The all-gather that
+reassembles the int16 metrics on every rank runs after the timed region at the shard's real size and is reported
+separately (`allgather`), through RCCL behind the library's own C ABI (hdp_allgather_dev) when the process group
+is nccl.  `--weak` gives every rank the full grid instead (labelled "weak").
+
+Inputs are resident in HBM when a kernel span starts.  At N = 1 the C3 grid does not fit (baseline + measure =
+303 GB > 288 GB), so a step walks two resident bands of cells; every band gets ITS OWN series (its cells'
+latitudes and cell offset), regenerated on the device between the event-timed kernel spans, and `ms_per_step`
+is then the sum of the kernel spans (HIP events on the launch stream), with the wall clock of the loop reported
+beside it (`wall_ms_per_step`).  With one band per rank (every N >= 2 shard of C3) nothing is regenerated and
+`ms_per_step` is the wall clock between the two fences.
+
+torch is plumbing here (process group, barrier, device buffers whose raw pointers go to the C ABI).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -37,14 +46,15 @@ PERCENTILES_C5 = np.linspace(0.80, 0.99, 20)
 DEFINITIONS_C5 = [[d, b, b] for d in (3, 4, 5, 6) for b in (0, 1, 2)]
 CONFIGS = {
     # name: (years, n_lat, n_lon, ensemble members, percentiles, definitions)
-    "c3": (100, 720, 1440, 1, PERCENTILES, DEFINITIONS),  # BASELINE.json configs[2], the config the target is quoted on
+    "c3": (100, 720, 1440, 1, PERCENTILES, DEFINITIONS),  # BASELINE.json configs[2] (N = 1) and configs[3] (N = 8)
     "c2": (10, 180, 360, 1, PERCENTILES, DEFINITIONS),    # configs[1]: 3650 d x 180 x 360
     # configs[4]: 10 members x 36500 d x 192 x 288; members are concatenated along time for the thresholds
-    # (threshold.py:114-119) and share their cell's thresholds in the metrics pass
+    # (threshold.py:114-119) and share their cell's thresholds in the metrics pass; members of a cell stay on one GPU
     "c5": (100, 192, 288, 10, PERCENTILES_C5, DEFINITIONS_C5),
     "tiny": (10, 16, 32, 1, PERCENTILES, DEFINITIONS),
     "tiny5": (10, 8, 16, 3, PERCENTILES_C5, DEFINITIONS_C5),
 }
+PARITY_CELLS = 1024   # cells of the parity sample, strided over every band of the rank's shard (>= 1000)
 
 
 def main():
@@ -53,9 +63,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("HDP_BENCH_CONFIG", "c3"), choices=sorted(CONFIGS))
-    ap.add_argument("--cells", type=int, default=0, help="override the number of grid cells per rank (debug)")
+    ap.add_argument("--cells", type=int, default=0, help="override the number of grid cells of the whole grid (debug)")
+    ap.add_argument("--weak", action="store_true", help="every rank processes the full grid (weak scaling)")
+    ap.add_argument("--layout", default="cm", choices=["cm", "tm"],
+                    help="cm: series-major [cell][T] inputs (the reference generator's layout, utils.py:82); "
+                         "tm: time-major [T][cell] inputs (CMIP order), transposed chunk by chunk on a second stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target time of the all-cores CPU baseline sample")
     ap.add_argument("--mem-fraction", type=float, default=0.88)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo only to rehearse the N>1 code path on a one-GPU box")
@@ -82,15 +96,25 @@ def main():
             dist.init_process_group("gloo")
 
     from hdp_amd import _lib, calendar as cal, core, utils
+    from hdp_amd import dist as hdist
 
     lib = _lib.ensure_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    ts = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(ts)
+    stream = ts.cuda_stream
 
-    years, n_lat, n_lon, M, PERCENTILES, DEFINITIONS = CONFIGS[args.config]
+    years, n_lat, n_lon, M, PERC, DEFS = CONFIGS[args.config]
     T = years * 365
-    cells_rank = args.cells if args.cells > 0 else n_lat * n_lon   # weak scaling: full grid per rank
-    P, D = PERCENTILES.size, len(DEFINITIONS)
+    P, D = PERC.size, len(DEFS)
+    n_grid = args.cells if args.cells > 0 else n_lat * n_lon
+    if args.weak or world == 1:
+        c_lo, c_hi = 0, n_grid
+    else:
+        c_lo, c_hi = hdist.shard_bounds(n_grid, world, rank)     # contiguous cell range of this rank
+    cells_rank = c_hi - c_lo
+    scaling = "weak" if (args.weak and world > 1) else "strong"
+    grid_cells_total = n_grid * (world if scaling == "weak" else 1)
 
     # ---- host tables (the reference builds the same ones in Python: threshold.py:125, metric.py:410-416)
     dates = utils.noleap_date_range("2000-01-01", f"{2000 + years - 1}-12-31")
@@ -99,61 +123,80 @@ def main():
     north, south, season_years = cal.hemisphere_season_tables(dates)
     Y = north.shape[0]
     n_doy = time_index.shape[0]
-    tplan = core.ThresholdPlan(time_index, cols, PERCENTILES, M * T)
-    mplan = core.MetricsPlan(doy_map, n_doy, DEFINITIONS, north, south, P)
+    tplan = core.ThresholdPlan(time_index, cols, PERC, M * T)
+    mplan = core.MetricsPlan(doy_map, n_doy, DEFS, north, south, P)
     Yp = mplan.year_pitch
 
     # ---- bands: the largest equal split of this rank's cells whose buffers fit in HBM ----------------
     per_cell = 2 * M * T * 4 + n_doy * P * 8 + M * (4 * P * D * Yp * 2 + 1) + 4
+    if args.layout == "tm":
+        per_cell += 0   # the time-major sources are transposed into the same [cell][T] buffers chunk by chunk
     free_b, total_b = torch.cuda.mem_get_info(dev)
     budget = int(free_b * args.mem_fraction)
     n_bands = 1
-    while (cells_rank + n_bands - 1) // n_bands * per_cell > budget:
+    while (max(cells_rank, 1) + n_bands - 1) // n_bands * per_cell > budget:
         n_bands += 1
-    bc = (cells_rank + n_bands - 1) // n_bands
-    cells_rank_eff = bc * n_bands   # equal bands (== cells_rank for the named configs)
+    bc = (max(cells_rank, 1) + n_bands - 1) // n_bands            # cells per band (the last band may own fewer)
+    band_cells = [max(0, min(bc, cells_rank - b * bc)) for b in range(n_bands)]
 
     def raw(nbytes):
-        return torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        return torch.empty(int(max(nbytes, 16)), dtype=torch.uint8, device=dev)
 
     # baseline [cell][M * T] (members appended along time); measure [member][cell][T] = M * bc series
     xb, xm = raw(bc * M * T * 4), raw(M * bc * T * 4)
     thr = raw(bc * n_doy * P * 8)
-    out = torch.empty(4 * P * D * M * bc * Yp, dtype=torch.int16, device=dev)
-    # latitude of every cell of this rank's grid, row-major (lat, lon); band b owns cells [b*bc, (b+1)*bc)
+    out = torch.empty(max(4 * P * D * M * bc * Yp, 8), dtype=torch.int16, device=dev)
+    # latitude of every cell of the grid, row-major (lat, lon); this rank owns grid cells [c_lo, c_hi)
     lat_axis = np.linspace(-90.0, 90.0, n_lat)
-    cell_ids = np.arange(cells_rank_eff) % (n_lat * n_lon)
-    lat_cells = lat_axis[cell_ids // n_lon].astype(np.float32)
-    lat_dev = torch.from_numpy(np.tile(lat_cells[:bc], M)).to(dev)
-    south_dev = [torch.from_numpy(np.tile((lat_cells[b * bc:(b + 1) * bc] < 0).astype(np.uint8), M)).to(dev)
-                 for b in range(n_bands)]
+    grid_ids = (c_lo + np.arange(max(cells_rank, 1))) % (n_lat * n_lon)
+    lat_cells = lat_axis[grid_ids // n_lon].astype(np.float32)      # [cells_rank]
+    lat_dev, south_dev = [], []
+    for b in range(n_bands):
+        lc = lat_cells[b * bc: b * bc + max(band_cells[b], 1)]
+        lat_dev.append(torch.from_numpy(np.tile(lc, M)).to(dev))
+        south_dev.append(torch.from_numpy(np.tile((lc < 0).astype(np.uint8), M)).to(dev))
 
-    # synthetic inputs, generated on the device (reference generator formula + hashed noise):
-    # baseline = control, measure = control + warming trend (hdp/utils.py:41: t / (365*100))
+    # synthetic inputs, generated on the device (reference generator formula + hashed noise of (seed, cell, t)):
+    # baseline = control, measure = control + warming trend (hdp/utils.py:41: t / (365*100)).  cell_offset makes
+    # the noise a function of the GRID cell, so every sharding of the grid sees the same data.
     seed = 0
-    _lib.check(lib.hdp_generate_series_dev(xb.data_ptr(), bc, M * T, rank * cells_rank_eff, lat_dev.data_ptr(),
-                                           seed, 0.7, 0.0, stream))
-    _lib.check(lib.hdp_generate_series_dev(xm.data_ptr(), M * bc, T, rank * cells_rank_eff * M, lat_dev.data_ptr(),
-                                           seed + 1, 0.7, 1.0 / 36500.0, stream))
-    torch.cuda.synchronize(dev)
+    weak_off = rank * n_grid if scaling == "weak" else 0
 
-    import ctypes
-    n_ev_steps = args.steps
+    def generate(b):
+        nb = band_cells[b]
+        if nb == 0:
+            return
+        off = weak_off + c_lo + b * bc
+        _lib.check(lib.hdp_generate_series_dev(xb.data_ptr(), nb, M * T, off, lat_dev[b].data_ptr(),
+                                               seed, 0.7, 0.0, stream))
+        _lib.check(lib.hdp_generate_series_dev(xm.data_ptr(), M * nb, T, off * M, lat_dev[b].data_ptr(),
+                                               seed + 1, 0.7, 1.0 / 36500.0, stream))
+
+    def run_band(b, ev=None):
+        nb = band_cells[b]
+        if ev:
+            lib.hdp_event_record(ev[0], stream)
+        if nb:
+            tplan.run(xb.data_ptr(), nb, thr.data_ptr(), stream)
+        if ev:
+            lib.hdp_event_record(ev[1], stream)
+        if nb:
+            mplan.run(xm.data_ptr(), thr.data_ptr(), nb, south_dev[b].data_ptr(), M * nb, out.data_ptr(), stream)
+        if ev:
+            lib.hdp_event_record(ev[2], stream)
+
+    generate(0)
+    torch.cuda.synchronize(dev)
     mplan.reserve(M * bc)   # exceedance scratch allocated before anything is timed
-    ev = [[[lib.hdp_event_create() for _ in range(3)] for _ in range(n_bands)] for _ in range(n_ev_steps)]
-    t_thr, t_met = [], []
+    regen = n_bands > 1     # every band gets its own series; regeneration sits outside the event-timed spans
+    ev = [[[lib.hdp_event_create() for _ in range(3)] for _ in range(n_bands)] for _ in range(args.steps)]
 
     def step(k):
         """k >= 0: timed step k (events recorded, read back after the timed region); k < 0: warm-up"""
         for b in range(n_bands):
-            if k >= 0:
-                lib.hdp_event_record(ev[k][b][0], stream)
-            tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
-            if k >= 0:
-                lib.hdp_event_record(ev[k][b][1], stream)
-            mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[b].data_ptr(), M * bc, out.data_ptr(), stream)
-            if k >= 0:
-                lib.hdp_event_record(ev[k][b][2], stream)
+            if regen:
+                generate(b)
+            run_band(b, ev[k][b] if k >= 0 else None)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -168,57 +211,64 @@ def main():
     for k in range(args.steps):
         step(k)
     fence()
-    elapsed = time.perf_counter() - t0
+    wall = time.perf_counter() - t0
     ms = ctypes.c_float()
+    t_thr, t_met = [], []
     for k in range(args.steps):
         for b in range(n_bands):
             e0, e1, e2 = ev[k][b]
             _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(ms))); t_thr.append(float(ms.value))
             _lib.check(lib.hdp_event_elapsed_ms(e1, e2, ctypes.byref(ms))); t_met.append(float(ms.value))
+    kernel_s = (sum(t_thr) + sum(t_met)) * 1e-3
+    timed = kernel_s if regen else wall          # see the module docstring
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        tt = torch.tensor([timed, wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = elapsed * 1e3 / max(1, args.steps)
-    cell_days_step = 2.0 * cells_rank_eff * M * T * world   # thresholds pass + metrics pass, all ranks
+        timed, wall = float(tt[0].item()), float(tt[1].item())
+    ms_per_step = timed * 1e3 / max(1, args.steps)
+    cell_days_step = 2.0 * grid_cells_total * M * T   # thresholds pass + metrics pass over the whole job's cells
     value = cell_days_step / (ms_per_step * 1e-3)
 
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / measured launch time --------
-    bytes_thr = bc * (4 * M * T + 8 * n_doy * P)
-    bytes_met = bc * (M * 4 * T + 8 * n_doy * P + M * 2 * 4 * Y * P * D)  # int16 metrics; thresholds shared by members
-    ms_thr, ms_met = float(np.mean(t_thr)), float(np.mean(t_met))
+    nb0 = band_cells[0]
+    bytes_thr = nb0 * (4 * M * T + 8 * n_doy * P)
+    bytes_met = nb0 * (M * 4 * T + 8 * n_doy * P + M * 2 * 4 * Y * P * D)  # int16 metrics; thresholds shared by members
+    full = [i for i in range(len(t_thr)) if band_cells[i % n_bands] == nb0] or [0]
+    ms_thr, ms_met = float(np.mean([t_thr[i] for i in full])), float(np.mean([t_met[i] for i in full]))
     kern = {
         "thresholds_kernel": {"ms_per_launch": ms_thr, "algorithmic_bytes": bytes_thr,
                               "GBps": bytes_thr / ms_thr / 1e6, "frac_hbm": bytes_thr / ms_thr / 1e6 / HBM_PEAK_GBS,
-                              "cell_days_per_s": bc * M * T / (ms_thr * 1e-3)},
+                              "cell_days_per_s": nb0 * M * T / (ms_thr * 1e-3), "kernel": tplan.describe()},
         "metrics_kernel": {"ms_per_launch": ms_met, "algorithmic_bytes": bytes_met,
                            "GBps": bytes_met / ms_met / 1e6, "frac_hbm": bytes_met / ms_met / 1e6 / HBM_PEAK_GBS,
-                           "cell_days_per_s": bc * M * T / (ms_met * 1e-3)},
+                           "cell_days_per_s": nb0 * M * T / (ms_met * 1e-3), "kernel": mplan.describe()},
     }
     dom = "thresholds_kernel" if ms_thr >= ms_met else "metrics_kernel"
-    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process,
-    # so the per-cell figure measured with rocprofv3 (profiles/traffic_per_cell.json, same workload
-    # shape) is scaled to the cells of one launch; null when no profile matches this workload.
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process, so the per-cell
+    # figure measured with rocprofv3 for THIS build and workload (profiles/traffic_per_cell.json: FETCH_SIZE doubled as
+    # the guide prescribes for gfx950, + WRITE_SIZE, separate --pmc passes) is scaled to the cells of one launch; null
+    # when the file does not describe this workload and kernel.
     traffic = None
     try:
         tp = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_cell.json")))
-        if tp.get("workload") == args.config:
-            traffic = float(tp[dom]["bytes_per_cell"]) * bc
+        if tp.get("workload") == args.config and tp[dom].get("kernel", "") in kern[dom]["kernel"]:
+            traffic = float(tp[dom]["bytes_per_cell"]) * nb0
     except Exception:
         traffic = None
-    dom_name = {"thresholds_kernel": tplan.describe() + ", one launch per band",
-                "metrics_kernel": "exceed_kernel + metrics_kernel_cells16 (batches of series, two overlapping launches per batch, timed together)"}[dom]
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kern[dom]["frac_hbm"], "traffic": traffic,
-                "traffic_source": "rocprofv3 FETCH_SIZE/WRITE_SIZE per cell (profiles/) x cells per launch",
+                "traffic_source": "rocprofv3 2 x FETCH_SIZE + WRITE_SIZE per cell (profiles/traffic_per_cell.json) x cells per launch",
                 "both_kernels_frac": (bytes_thr + bytes_met) / (ms_thr + ms_met) / 1e6 / HBM_PEAK_GBS,
-                "measured_copy_ceiling": HBM_COPY_GBS}
+                "measured_copy_ceiling": HBM_COPY_GBS,
+                "note": "thresholds performance depends on the requested quantiles: the merge walks down to the deepest "
+                        "requested rank from the nearer end of the window (q = 0.90 of 1500 samples: 151 steps per row; "
+                        "q = 0.5 would walk 750)"}
 
     # ---- pre-step: fused Celsius -> heat index -> Celsius kernel, reported beside `value`
     pre_step = None
     if rank == 0:
         try:
-            n_el = int(min(bc * T, thr.numel() // 4, out.numel() // 2, 1 << 30)) & ~3
+            n_el = int(min(nb0 * T, thr.numel() // 4, out.numel() // 2, 1 << 30)) & ~3
             e0, e1 = lib.hdp_event_create(), lib.hdp_event_create()
             rh_buf = thr[: n_el * 4]      # reuse resident scratch as (arbitrary) humidity / output operands
             lib.hdp_heat_index_celsius_f32_dev(xm.data_ptr(), rh_buf.data_ptr(), n_el, out.data_ptr(), stream)
@@ -235,61 +285,20 @@ def main():
         except Exception as e:   # reported beside `value`; must not cost the bench line
             pre_step = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    # ---- post-step: latitude-weighted spatial mean of the resident int16 metrics, one row per
-    # (metric, percentile, definition, season) over this band's series; reported beside `value`
-    post_step = None
-    if rank == 0:
+    # ---- time-major inputs (CMIP order [T][cell]): the chunk-pipelined device path ----------------
+    layout_tm = None
+    if rank == 0 and args.layout == "tm":
         try:
-            n_rows, n_ser = 4 * P * D * int(Yp), M * bc
-            w_dev = torch.from_numpy(np.cos(np.deg2rad(np.tile(lat_cells[:bc], M).astype(np.float64)))).to(dev)
-            mean_dev = torch.empty(n_rows, dtype=torch.float64, device=dev)
-            e0, e1 = lib.hdp_event_create(), lib.hdp_event_create()
-            _lib.check(lib.hdp_weighted_mean_i16_dev(out.data_ptr(), n_rows, n_ser, w_dev.data_ptr(), mean_dev.data_ptr(), stream))
-            lib.hdp_event_record(e0, stream)
-            reps = 3
-            for _ in range(reps):
-                _lib.check(lib.hdp_weighted_mean_i16_dev(out.data_ptr(), n_rows, n_ser, w_dev.data_ptr(), mean_dev.data_ptr(), stream))
-            lib.hdp_event_record(e1, stream)
-            wms = ctypes.c_float()
-            _lib.check(lib.hdp_event_elapsed_ms(e0, e1, ctypes.byref(wms)))
-            gbps = (2.0 * n_rows * n_ser + 8.0 * n_ser + 8.0 * n_rows) * reps / (wms.value * 1e-3) / 1e9
-            post_step = {"kernel": "weighted_rows_mean_i16x8_kernel", "rows": n_rows, "series": n_ser,
-                         "ms": wms.value / reps, "GBps": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
-            del w_dev, mean_dev
+            layout_tm = bench_time_major(lib, torch, dev, stream, tplan, mplan, xb, xm, thr, out, south_dev[0],
+                                         nb0, M, T, n_doy, P, ms_thr, ms_met)
         except Exception as e:
-            post_step = {"error": f"{type(e).__name__}: {e}"[:300]}
+            layout_tm = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    # ---- RCCL all-gather of the metrics (reassembly step of north_star), reported separately ------------
-    allgather = None
-    if world > 1:
-        try:
-            total_c4 = 4 * P * D * (n_lat * n_lon) * Yp              # the C3/C4 grid's int16 metrics, elements
-            share = min(out.numel(), total_c4 // 8)                   # the per-GPU shard of config 4
-            free_b, _ = torch.cuda.mem_get_info(dev)
-            share = int(min(share, free_b * 0.8 / 2 / world))
-            if args.backend != "nccl":   # rehearsal path: gloo moves host bytes
-                share = min(share, 1 << 24)
-            share &= ~3                                               # whole 8-byte words
-            gdev = dev if args.backend == "nccl" else torch.device("cpu")
-            gathered = torch.empty(share * world, dtype=torch.int16, device=gdev)
-            # RCCL has no int16 type: the bytes travel as int64 words (also keeps the element count of a 6 GB shard
-            # well inside 32 bits)
-            g8, o8 = gathered.view(torch.int64), out[:share].to(gdev).view(torch.int64)
-            dist.all_gather_into_tensor(g8, o8)
-            fence()
-            t1 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                dist.all_gather_into_tensor(g8, o8)
-            fence()
-            dt = (time.perf_counter() - t1) / reps
-            allgather = {"bytes_per_rank": share * 2, "ms": dt * 1e3,
-                         "recv_GBps_per_gpu": share * 2 * (world - 1) / dt / 1e9}
-            del gathered
-        except Exception as e:   # the reassembly step is reported beside `value`; it must not cost the bench line
-            allgather = {"error": f"{type(e).__name__}: {e}"[:300]}
-
-    # ---- CPU baseline: the C restatement of the reference algorithm on a bounded sample, rank 0 only ----
+    # ---- parity sample + CPU baseline ---------------------------------------------------------------------------
+    # PARITY_CELLS cells strided over EVERY band of this rank's shard (both hemispheres at N = 1): their series are
+    # copied out of the device buffers the kernels read, the kernels' own outputs for them are copied out, and the C
+    # restatement of the reference algorithm (oracle/) recomputes them on the host: bit-exact or the line says so.
+    # The same sample, timed, is the all-cores CPU baseline; a smaller one gives the 1-thread figure.
     cpu = None
     parity = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -297,59 +306,180 @@ def main():
             from oracle import c_oracle
             cores = c_oracle.max_threads()
             win = cal.expand_window_table(time_index, cols)
-            xb_h = lambda n: xb[: n * M * T * 4].cpu().numpy().view(np.float32).reshape(n, M * T)  # noqa: E731
-            # the M members of the first n cells, member-major like the device buffer
-            xm_h = lambda n: (xm.view(torch.float32).view(M, bc, T)[:, :n].cpu().numpy()  # noqa: E731
-                              .reshape(M * n, T))
-            thr_m = lambda th: np.concatenate([th] * M)                                     # noqa: E731
-            hemi_m = lambda n: np.tile((lat_cells[:n] < 0).astype(np.uint8), M)             # noqa: E731
-            n0 = min(bc, cores)
+            per_band = max(1, PARITY_CELLS // n_bands)
+            xs_b, xs_m, th_g, met_g, hemi = [], [], [], [], []
+            for b in range(n_bands):
+                nb = band_cells[b]
+                if nb == 0:
+                    continue
+                if regen or b > 0:
+                    generate(b)
+                run_band(b)
+                torch.cuda.synchronize(dev)
+                idx = np.unique(np.linspace(0, nb - 1, min(per_band, nb)).astype(np.int64))
+                it = torch.from_numpy(idx).to(dev)
+                xs_b.append(xb[: nb * M * T * 4].view(torch.float32).view(nb, M * T)[it].cpu().numpy())
+                xs_m.append(xm[: M * nb * T * 4].view(torch.float32).view(M, nb, T)[:, it].cpu().numpy())  # [M, n, T]
+                # device layouts: thresholds [cell][P][n_doy]; metrics [4][P][D][Y][M * nb] (series-minor)
+                th_g.append(thr[: nb * n_doy * P * 8].view(torch.float64).view(nb, P, n_doy)[it].cpu().numpy()
+                            .transpose(0, 2, 1))
+                og = out[: 4 * P * D * Y * M * nb].view(4, P, D, Y, M, nb)[..., it].cpu().numpy()   # [4,P,D,Y,M,n]
+                met_g.append(np.transpose(og, (1, 2, 4, 5, 0, 3)))                                   # [P,D,M,n,4,Y]
+                hemi.append((lat_cells[b * bc + idx] < 0).astype(np.uint8))
+            xs_b = np.concatenate(xs_b)
+            th_gpu = np.concatenate(th_g)
+            ns = xs_b.shape[0]
+            xs_m = np.concatenate(xs_m, axis=1).reshape(M * ns, T)          # member-major, like the device buffer
+            met_gpu = np.concatenate(met_g, axis=3).reshape(P, D, M * ns, 4, Y).astype(np.int64)
+            hemi = np.tile(np.concatenate(hemi), M)
+            n_south = int(hemi[:ns].sum())
             tc = time.perf_counter()
-            th0 = c_oracle.thresholds(xb_h(n0), win, PERCENTILES)
-            c_oracle.metrics(xm_h(n0), thr_m(th0), doy_map, DEFINITIONS, north, south, hemi_m(n0))
-            per_round = time.perf_counter() - tc
-            rounds = int(max(1, min(64, args.cpu_seconds / max(per_round, 1e-3))))
-            ns = min(bc, n0 * rounds)
-            tc = time.perf_counter()
-            th_cpu = c_oracle.thresholds(xb_h(ns), win, PERCENTILES)
-            met_cpu = c_oracle.metrics(xm_h(ns), thr_m(th_cpu), doy_map, DEFINITIONS, north, south, hemi_m(ns))
+            th_cpu = c_oracle.thresholds(xs_b, win, PERC)
+            met_cpu = c_oracle.metrics(xs_m, np.concatenate([th_cpu] * M), doy_map, DEFS, north, south, hemi)
             cpu_s = time.perf_counter() - tc
+            parity = {"cells": int(ns), "southern_cells": n_south, "northern_cells": int(ns - n_south),
+                      "bands_sampled": int(sum(1 for c in band_cells if c)),
+                      "thresholds_bit_exact": bool(np.array_equal(th_gpu, th_cpu, equal_nan=True)),
+                      "metrics_bit_exact": bool(np.array_equal(met_gpu, met_cpu))}
+            # 1-thread figure on a few cells of the same sample
+            n1 = int(max(1, min(ns, 8)))
+            one = c_oracle.set_threads(1)
+            t1 = time.perf_counter()
+            th1 = c_oracle.thresholds(xs_b[:n1], win, PERC)
+            c_oracle.metrics(xs_m.reshape(M, ns, T)[:, :n1].reshape(M * n1, T), np.concatenate([th1] * M), doy_map,
+                             DEFS, north, south, np.tile(hemi[:n1], M))
+            one_s = time.perf_counter() - t1
+            c_oracle.set_threads(cores)
             cpu = None if world > 1 else {   # reported at N = 1 only (torchrun pins OMP_NUM_THREADS=1)
                 "value": 2.0 * ns * M * T / cpu_s, "unit": "cell-days/s", "cores": cores, "kind": "port",
-                   "sample": f"first {ns} cells of band 0 of the same workload (T={T}, P={P}, D={D}), both passes, "
-                          f"{cpu_s:.1f} s; oracle/hdp_oracle.c (reference algorithm restated in C, OpenMP over cells)"}
-            # the same sample doubles as a parity spot-check of what the timed kernels produced (band 0 flags)
-            tplan.run(xb.data_ptr(), bc, thr.data_ptr(), stream)
-            mplan.run(xm.data_ptr(), thr.data_ptr(), bc, south_dev[0].data_ptr(), M * bc, out.data_ptr(), stream)
-            torch.cuda.synchronize(dev)
-            # device layout [cell][P][n_doy] -> the reference's (cell, doy, percentile)
-            th_gpu = thr[: ns * n_doy * P * 8].cpu().numpy().view(np.float64).reshape(ns, P, n_doy).transpose(0, 2, 1)
-            # device layout [4][P][D][Y][series] -> the reference's (percentile, definition, series, metric, year)
-            out_gpu = out.view(4, P * D, Y, M, bc)[..., :ns].cpu().numpy()
-            met_gpu = np.transpose(out_gpu.reshape(4, P, D, Y, M * ns), (1, 2, 4, 0, 3)).astype(np.int64)
-            parity = {"cells": ns, "thresholds_bit_exact": bool(np.array_equal(th_gpu, th_cpu)),
-                      "metrics_bit_exact": bool(np.array_equal(met_gpu, met_cpu))}
+                "sample": f"{ns} cells strided over the {n_bands} band(s) of the same workload (T={T}, P={P}, D={D}), both "
+                          f"passes, {cpu_s:.1f} s; oracle/hdp_oracle.c (reference algorithm restated in C, OpenMP over cells)",
+                "one_thread": {"value": 2.0 * n1 * M * T / one_s, "unit": "cell-days/s", "cores": int(one),
+                               "sample": f"first {n1} cells of that sample, {one_s:.1f} s"}}
         except Exception as e:   # the checker must not cost the bench line
             parity = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    # ---- all-gather of the metrics (reassembly step of north_star), reported separately -----------------------
+    allgather = None
+    if world > 1:
+        try:
+            allgather = bench_allgather(lib, torch, dist, hdist, dev, stream, args, out, world, rank, fence,
+                                        4 * P * D * Yp * M * bc)
+        except Exception as e:   # the reassembly step is reported beside `value`; it must not cost the bench line
+            allgather = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         line = {
             "metric": "grid-cell-days/sec for compute_thresholds+compute_group_metrics",
             "value": value, "unit": "cell-days/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {f'{M} members x ' if M > 1 else ''}{T} d x {n_lat} x {n_lon} fp32, {P} percentiles x {D} definitions, "
-                                   f"window radius 7, noleap, per GPU",
-                       "cells_per_gpu": int(cells_rank_eff), "members": M, "T": T, "percentiles": P, "definitions": D,
-                       "seasons": int(Y), "resident_bands_per_step": n_bands, "cells_per_band": int(bc),
-                       "sharding": "independent grid cells per rank, no data-path collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "pre_step": pre_step, "post_step": post_step, "allgather": allgather,
-            "parity_sample": parity, "device": _lib.device_info(),
+                                   f"window radius 7, noleap" + (f" ({n_grid} cells)" if args.cells else ""),
+                       "grid_cells": int(n_grid), "cells_per_gpu": int(cells_rank), "members": M, "T": T, "percentiles": P,
+                       "definitions": D, "seasons": int(Y), "resident_bands_per_step": n_bands, "cells_per_band": int(bc),
+                       "band_data": ("every band has its own series (regenerated on the device between the event-timed kernel "
+                                     "spans; ms_per_step = sum of the spans)" if regen else "whole shard resident"),
+                       "layout": "series-major [cell][T]" if args.layout == "cm" else "series-major kernels; time-major variant in `layout_tm`",
+                       "sharding": ("one grid, contiguous cell ranges per rank (hdp_amd.dist.shard_bounds), no data-path collective"
+                                    if scaling == "strong" else "every rank processes the full grid")},
+            "wall_ms_per_step": wall * 1e3 / max(1, args.steps),
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "pre_step": pre_step, "layout_tm": layout_tm,
+            "allgather": allgather, "parity_sample": parity, "device": _lib.device_info(),
         }
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
+        if hdist.comm_world() > 1 or hdist.comm_ready():
+            hdist.comm_destroy()
         dist.destroy_process_group()
+
+
+def bench_time_major(lib, torch, dev, stream, tplan, mplan, xb, xm, thr, out, south, nb, M, T, n_doy, P, ms_thr, ms_met):
+    """Both passes from time-major [T][cell] sources (CMIP order; run_cmip_workflow.py:31-32): hdp_*_tm_dev transposes
+    chunks of cells on the plan's copy stream while the previous chunk computes.  Sources are built by transposing a slice
+    of the resident series-major inputs (so results can be compared), sized to the memory left."""
+    from hdp_amd import _lib
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    n = int(min(nb, max(1024, (free_b * 0.4) // (2 * M * T * 4))))
+    if M != 1:
+        return {"skipped": "time-major bench variant is wired for single-member configs"}
+    src_b = torch.empty((T, n), dtype=torch.float32, device=dev)
+    src_m = torch.empty((T, n), dtype=torch.float32, device=dev)
+    src_b.copy_(xb[: n * T * 4].view(torch.float32).view(n, T).t())
+    src_m.copy_(xm[: n * T * 4].view(torch.float32).view(n, T).t())
+    thr2 = torch.empty(n * n_doy * P, dtype=torch.float64, device=dev)
+    out_n = out.numel() // nb * n
+    out2 = torch.empty(out_n, dtype=torch.int16, device=dev)
+    tplan.run(xb.data_ptr(), n, thr.data_ptr(), stream)
+    mplan.run(xm.data_ptr(), thr.data_ptr(), n, south.data_ptr(), n, out.data_ptr(), stream)
+    ev = [lib.hdp_event_create() for _ in range(3)]
+    ms = ctypes.c_float()
+    res = {}
+    for it in range(2):   # first pass warms the plan's staging buffers
+        lib.hdp_event_record(ev[0], stream)
+        _lib.check(lib.hdp_thresholds_f32_tm_dev(tplan.handle, src_b.data_ptr(), n, n, thr2.data_ptr(), stream))
+        lib.hdp_event_record(ev[1], stream)
+        _lib.check(lib.hdp_metrics_f32_tm_dev(mplan.handle, src_m.data_ptr(), n, thr2.data_ptr(), n, south.data_ptr(), n,
+                                              out2.data_ptr(), stream))
+        lib.hdp_event_record(ev[2], stream)
+        _lib.check(lib.hdp_event_elapsed_ms(ev[0], ev[1], ctypes.byref(ms))); res["thresholds_ms"] = float(ms.value)
+        _lib.check(lib.hdp_event_elapsed_ms(ev[1], ev[2], ctypes.byref(ms))); res["metrics_ms"] = float(ms.value)
+    torch.cuda.synchronize(dev)
+    same_thr = bool(torch.equal(thr2.view(torch.int64), thr[: n * n_doy * P * 8].view(torch.int64)))
+    same_met = bool(torch.equal(out2.view(-1, n), out[: out_n].view(-1, n)))
+    scale = n / nb
+    res.update({"cells": n, "series_major_thresholds_ms_same_cells": ms_thr * scale, "series_major_metrics_ms_same_cells": ms_met * scale,
+                "cell_days_per_s": 2.0 * n * T / ((res["thresholds_ms"] + res["metrics_ms"]) * 1e-3),
+                "identical_to_series_major": same_thr and same_met,
+                "note": "includes the transposition of every chunk (read + write of the whole input, on a second stream "
+                        "beside the kernels)"})
+    return res
+
+
+def bench_allgather(lib, torch, dist, hdist, dev, stream, args, out, world, rank, fence, shard_elems):
+    """All-gather of the int16 metrics at this run's real shard size (config 4 at N = 8: 6.2 GB per rank).  With the
+    nccl backend the bytes go through the library's own RCCL communicator (hdp_comm_* / hdp_allgather_dev, the C ABI a
+    torch-free caller uses); the gloo rehearsal moves host bytes through torch.distributed."""
+    from hdp_amd import _lib
+    share = int(min(out.numel(), shard_elems))
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    share = int(min(share, free_b * 0.8 / 2 / world)) & ~3
+    if args.backend != "nccl":
+        share = min(share, 1 << 24)
+        gathered = torch.empty(share * world, dtype=torch.int16)
+        g8, o8 = gathered.view(torch.uint8), out[:share].cpu().view(torch.uint8)
+        dist.all_gather_into_tensor(g8, o8)
+        fence()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            dist.all_gather_into_tensor(g8, o8)
+        fence()
+        dt = (time.perf_counter() - t1) / reps
+        return {"path": "gloo rehearsal (host bytes)", "bytes_per_rank": share * 2, "ms": dt * 1e3}
+    # RCCL behind the C ABI: rank 0 makes the unique id, torch.distributed carries its 128 bytes to the other ranks
+    ident = torch.zeros(hdist.COMM_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        ident = torch.from_numpy(np.frombuffer(hdist.comm_unique_id(), dtype=np.uint8).copy())
+    idd = ident.to(dev)
+    dist.broadcast(idd, 0)
+    hdist.comm_init_rank(bytes(idd.cpu().numpy().tobytes()), rank, world)
+    gathered = torch.empty(share * world, dtype=torch.int16, device=dev)
+    res = {"path": "RCCL ncclAllGather behind hdp_allgather_dev", "bytes_per_rank": share * 2}
+    for name, fn in (("allgather", lib.hdp_allgather_dev), ("sendrecv", lib.hdp_allgather_direct_dev)):
+        _lib.check(fn(out.data_ptr(), share * 2, gathered.data_ptr(), stream))
+        fence()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            _lib.check(fn(out.data_ptr(), share * 2, gathered.data_ptr(), stream))
+        fence()
+        dt = (time.perf_counter() - t1) / reps
+        ok = bool(torch.equal(gathered[rank * share:(rank + 1) * share], out[:share]))
+        res[name] = {"ms": dt * 1e3, "recv_GBps_per_gpu": share * 2 * (world - 1) / dt / 1e9, "own_shard_intact": ok}
+    res["ms"] = res["allgather"]["ms"]
+    return res
 
 
 if __name__ == "__main__":

@@ -67,6 +67,16 @@ SIGNATURES = {
     "hdp_weighted_mean_i16_dev": (C.c_int, [vp, i64, i64, vp, vp, vp]),
     "hdp_weighted_mean_f64": (C.c_int, [vp, i64, i64, vp, vp]),
     "hdp_generate_series_dev": (C.c_int, [vp, i64, i64, i64, vp, C.c_uint64, f32, f32, vp]),
+    "hdp_metrics_plan_describe": (C.c_char_p, [vp]),
+    "hdp_thresholds_f32_tm_dev": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "hdp_metrics_f32_tm_dev": (C.c_int, [vp, vp, i64, vp, i64, vp, i64, vp, vp]),
+    "hdp_comm_unique_id": (C.c_int, [vp]),
+    "hdp_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int]),
+    "hdp_comm_destroy": (C.c_int, []),
+    "hdp_comm_rank": (C.c_int, []),
+    "hdp_comm_world": (C.c_int, []),
+    "hdp_allgather_dev": (C.c_int, [vp, sz, vp, vp]),
+    "hdp_allgather_direct_dev": (C.c_int, [vp, sz, vp, vp]),
 }
 
 _lib = None

@@ -247,8 +247,13 @@ class ThresholdPlan:
         """Device pointers; out is [n_cells][P][n_doy] float64 (percentile-major, what MetricsPlan.run reads)."""
         _lib.check(self.lib.hdp_thresholds_f32_dev(self.handle, x_ptr, int(n_cells), out_ptr, stream))
 
+    def run_time_major(self, x_tm_ptr, pitch_cells, n_cells, out_ptr, stream=None):
+        """x_tm is [T][pitch_cells] float32 on the device (CMIP order); output as run()."""
+        _lib.check(self.lib.hdp_thresholds_f32_tm_dev(self.handle, x_tm_ptr, int(pitch_cells), int(n_cells), out_ptr,
+                                                      stream))
+
     def describe(self):
-        """The kernel a launch runs now (plan choice under the HDP_THR_* switches)."""
+        """The kernel a launch runs (plan choice under the HDP_THR_* switches at plan creation)."""
         return self.lib.hdp_threshold_plan_describe(self.handle).decode()
 
     def __del__(self):
@@ -286,6 +291,14 @@ class MetricsPlan:
         """Device pointers; thr is [n_thr_cells][P][n_doy] float64 as written by ThresholdPlan.run."""
         _lib.check(self.lib.hdp_metrics_f32_dev(self.handle, x_ptr, thr_ptr, int(n_thr_cells), is_south_ptr,
                                                 int(n_cells), out_ptr, stream))
+
+    def run_time_major(self, x_tm_ptr, pitch_cells, thr_ptr, n_thr_cells, is_south_ptr, n_cells, out_ptr, stream=None):
+        """x_tm is [T][pitch_cells] float32 on the device (CMIP order); output as run()."""
+        _lib.check(self.lib.hdp_metrics_f32_tm_dev(self.handle, x_tm_ptr, int(pitch_cells), thr_ptr, int(n_thr_cells),
+                                                   is_south_ptr, int(n_cells), out_ptr, stream))
+
+    def describe(self):
+        return self.lib.hdp_metrics_plan_describe(self.handle).decode()
 
     def __del__(self):
         try:

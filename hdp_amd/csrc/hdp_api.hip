@@ -3,6 +3,8 @@
 // stage caller buffers through HBM in bounded chunks.
 #include "hdp_internal.hpp"
 
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cmath>
 #include <future>
@@ -426,6 +428,8 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
     dd[i] = (int32_t)defs[i];
   }
   std::vector<int2> ss(std::max<int64_t>(1, 2 * Y));
+  std::vector<int64_t> r64(std::max<int64_t>(1, 4 * Y));
+  bool ordered = true;
   for (int h = 0; h < 2; ++h) {
     const int64_t *r = h ? south : north;
     int64_t prev_end = 0;
@@ -436,20 +440,32 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
                   "zero-size array to reduction operation maximum which has no identity "
                   "(season %lld of the %s table is [%lld, %lld))",
                   (long long)y, h ? "southern" : "northern", (long long)a, (long long)b);
-      HDP_REQUIRE(a >= prev_end, HDP_EUNSUP,
-                  "season ranges must be increasing and disjoint for the fused metrics kernel");
+      // tables that are not increasing and disjoint (the reference takes any ranges, its unit tests use overlapping
+      // ones) are served by the per-series path, launch_metrics_any_ranges
+      if (a < prev_end) ordered = false;
       HDP_REQUIRE(b - a < 32768, HDP_EUNSUP, "season longer than 32767 days does not fit int16");
-      prev_end = b;
+      prev_end = std::max(prev_end, b);
       ss[h * Y + y] = make_int2((int)a, (int)b);
+      r64[(h * Y + y) * 2] = a;
+      r64[(h * Y + y) * 2 + 1] = b;
     }
   }
   auto *pl = new hdp_metrics_plan();
   pl->T = T; pl->n_doy = n_doy; pl->D = D; pl->Y = Y; pl->P = P;
+  pl->ordered_seasons = ordered;
+  pl->defs_host.assign(defs, defs + D * 3);
+  // HDP_METRICS_* selectors: read here, once (tests and A/B runs; every value gives the same results)
+  pl->opt_general = env_option("HDP_METRICS_GENERAL", 0) != 0;
+  pl->opt_fused = env_option("HDP_METRICS_FUSED", 0) != 0;
+  pl->opt_cells = env_option("HDP_METRICS_CELLS", 1) != 0;
+  pl->opt_packed = env_option("HDP_METRICS_PACKED", 1) != 0;
+  pl->opt_overlap = env_option("HDP_METRICS_OVERLAP", 1) != 0;
+  pl->opt_batch = std::max<long long>(0, env_option("HDP_METRICS_BATCH", 0));
   pl->Ypitch = (Y + 15) & ~int64_t(15);  // 32-byte rows: sector-aligned packed stores
   int64_t dmax = 1;
   for (int64_t d = 0; d < D; ++d) dmax = std::max<int64_t>(dmax, dd[3 * d]);
   pl->dmax = dmax;
-  bool uniform = dmax < (int64_t(1) << 20);
+  bool uniform = ordered && dmax < (int64_t(1) << 20);
   for (int h = 0; h < 2 && uniform; ++h)
     for (int64_t y = 0; y + 1 < Y; ++y)
       if (ss[h * Y + y + 1].x - ss[h * Y + y].y < dmax + 64) uniform = false;
@@ -462,6 +478,7 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   hipError_t e = pl->doy_map.upload(dm.data(), dm.size() * 2);
   if (e == hipSuccess) e = pl->defs.upload(dd.data(), dd.size() * 4);
   if (e == hipSuccess) e = pl->seasons.upload(ss.data(), ss.size() * sizeof(int2));
+  if (e == hipSuccess) e = pl->ranges64.upload(r64.data(), r64.size() * 8);
   if (e != hipSuccess) {
     delete pl;
     return set_error(HDP_EHIP, "uploading metrics plan tables failed: %s", hipGetErrorString(e));
@@ -578,6 +595,128 @@ int hdp_metrics_f32_planes_i64(const float *x, int64_t n_cells, int64_t T, int64
                                const int64_t *south, const uint8_t *is_south, int64_t Y, int64_t *out) {
   return metrics_host(x, n_cells, T, stride_cell, stride_time, thr, n_thr_cells, n_doy, P, doy_map, defs, D, north,
                       south, is_south, Y, out, true);
+}
+
+const char *hdp_metrics_plan_describe(const hdp_metrics_plan *plan) {
+  static thread_local char buf[256];
+  if (!plan) return "";
+  if (!plan->ordered_seasons)
+    snprintf(buf, sizeof buf, "per-series kernels (hot days, index_heatwaves, season metrics): season tables overlap or are unordered");
+  else if (!plan->uniform_seasons || plan->opt_general)
+    snprintf(buf, sizeof buf, "metrics_kernel_general (seasons closed per lane)");
+  else if (plan->opt_fused)
+    snprintf(buf, sizeof buf, "metrics_kernel_uniform<fused> (one kernel, no exceedance scratch)");
+  else if (!plan->opt_cells)
+    snprintf(buf, sizeof buf, "exceed_kernel + metrics_kernel_uniform (lane = (percentile, definition)) + transpose");
+  else
+    snprintf(buf, sizeof buf, "exceed_kernel + metrics_kernel_cells%s (lane = series; batches of series, the two kernels of "
+             "consecutive batches overlap on the plan's streams)",
+             (plan->defs_fit16 && plan->T <= 65535 && plan->opt_packed) ? "16 (packed 16-bit state)" : "");
+  return buf;
+}
+
+// ---- time-major device input (CMIP order [T][cells]; reference workflow docs/example_cmip_workflow/run_cmip_workflow.py:31-32)
+
+int hdp_thresholds_f32_tm_dev(const hdp_threshold_plan *plan, const float *x_tm_dev, int64_t pitch_cells, int64_t n_cells,
+                              double *out_dev, void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(plan && (n_cells == 0 || (x_tm_dev && out_dev)), HDP_EINVAL, "NULL plan or buffer");
+  HDP_REQUIRE(n_cells >= 0 && pitch_cells >= n_cells, HDP_EINVAL, "bad cell count or pitch");
+  return launch_thresholds_tm(plan, x_tm_dev, pitch_cells, n_cells, out_dev, pick(stream));
+}
+
+int hdp_metrics_f32_tm_dev(const hdp_metrics_plan *plan, const float *x_tm_dev, int64_t pitch_cells, const double *thr_dev,
+                           int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells, int16_t *out_dev,
+                           void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(plan, HDP_EINVAL, "NULL plan");
+  HDP_REQUIRE(n_cells >= 0 && n_thr_cells > 0 && pitch_cells >= n_cells && pitch_cells > 0, HDP_EINVAL, "bad cell counts");
+  HDP_REQUIRE(n_cells == 0 || (x_tm_dev && thr_dev && is_south_dev), HDP_EINVAL, "NULL buffer");
+  if (plan->Y == 0 || n_cells == 0) return HDP_OK;
+  HDP_REQUIRE(out_dev, HDP_EINVAL, "NULL output");
+  return launch_metrics(plan, x_tm_dev, thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev, pick(stream), pitch_cells);
+}
+
+// ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------------------------
+// north_star: "grid cells shard embarrassingly across the 8 GPUs of one node with an RCCL all-gather over xGMI only to
+// reassemble the final metrics Dataset".  The reference has no collective of its own (its data movement is implicit in
+// the dask graph: xarray.map_blocks threshold.py:161, metric.py:444; concat/merge threshold.py:229, metric.py:520).
+
+static ncclComm_t g_comm = nullptr;
+static int g_comm_rank = -1, g_comm_world = 0;
+
+int hdp_comm_unique_id(void *id_out) {
+  static_assert(sizeof(ncclUniqueId) == HDP_COMM_ID_BYTES, "ncclUniqueId size");
+  HDP_REQUIRE(id_out, HDP_EINVAL, "NULL id buffer");
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  ncclUniqueId id;
+  const ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return set_error(HDP_EHIP, "ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+  std::memcpy(id_out, &id, sizeof id);
+  return HDP_OK;
+}
+
+int hdp_comm_init_rank(const void *id_bytes, int rank, int world) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(id_bytes && world >= 1 && rank >= 0 && rank < world, HDP_EINVAL, "bad communicator arguments");
+  HDP_REQUIRE(g_comm == nullptr, HDP_EINVAL, "a communicator already exists (hdp_comm_destroy first)");
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof id);
+  const ncclResult_t r = ncclCommInitRank(&g_comm, world, id, rank);
+  if (r != ncclSuccess) {
+    g_comm = nullptr;
+    return set_error(HDP_EHIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(r));
+  }
+  g_comm_rank = rank;
+  g_comm_world = world;
+  return HDP_OK;
+}
+
+int hdp_comm_destroy(void) {
+  if (g_comm) (void)ncclCommDestroy(g_comm);
+  g_comm = nullptr;
+  g_comm_rank = -1;
+  g_comm_world = 0;
+  return HDP_OK;
+}
+
+int hdp_comm_rank(void) { return g_comm_rank; }
+int hdp_comm_world(void) { return g_comm_world; }
+
+// recv_dev [world][bytes_per_rank] <- every rank's send_dev [bytes_per_rank].  Bytes travel as ncclInt8 (RCCL has no
+// int16): the int16 metrics shard of config 4 is 6.2 GB per rank.
+int hdp_allgather_dev(const void *send_dev, size_t bytes_per_rank, void *recv_dev, void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(g_comm, HDP_EINVAL, "no communicator (hdp_comm_init_rank)");
+  HDP_REQUIRE(bytes_per_rank == 0 || (send_dev && recv_dev), HDP_EINVAL, "NULL buffer");
+  if (bytes_per_rank == 0) return HDP_OK;
+  const ncclResult_t r = ncclAllGather(send_dev, recv_dev, bytes_per_rank, ncclInt8, g_comm, pick(stream));
+  if (r != ncclSuccess) return set_error(HDP_EHIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
+  return HDP_OK;
+}
+
+// The same exchange as one grouped send/recv per peer: on the full xGMI mesh (7 links x ~153 GB/s per GPU) every
+// peer's shard can cross its own link at once, where a ring all-gather is bound by one link.  Which of
+// the two is faster is a measurement for an 8-GPU node; bench.py reports both.
+int hdp_allgather_direct_dev(const void *send_dev, size_t bytes_per_rank, void *recv_dev, void *stream) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(g_comm, HDP_EINVAL, "no communicator (hdp_comm_init_rank)");
+  HDP_REQUIRE(bytes_per_rank == 0 || (send_dev && recv_dev), HDP_EINVAL, "NULL buffer");
+  if (bytes_per_rank == 0) return HDP_OK;
+  hipStream_t s = pick(stream);
+  char *recv = static_cast<char *>(recv_dev);
+  ncclResult_t r = ncclGroupStart();
+  for (int peer = 0; r == ncclSuccess && peer < g_comm_world; ++peer) {
+    if (peer == g_comm_rank) continue;
+    r = ncclSend(send_dev, bytes_per_rank, ncclInt8, peer, g_comm, s);
+    if (r == ncclSuccess) r = ncclRecv(recv + size_t(peer) * bytes_per_rank, bytes_per_rank, ncclInt8, peer, g_comm, s);
+  }
+  const ncclResult_t e = ncclGroupEnd();
+  if (r == ncclSuccess) r = e;
+  if (r != ncclSuccess) return set_error(HDP_EHIP, "grouped ncclSend/ncclRecv failed: %s", ncclGetErrorString(r));
+  HDP_HIP_TRY(hipMemcpyAsync(recv + size_t(g_comm_rank) * bytes_per_rank, send_dev, bytes_per_rank,
+                             hipMemcpyDeviceToDevice, s));
+  return HDP_OK;
 }
 
 // ---- unit-level mirrors ---------------------------------------------------------------------------------

@@ -114,9 +114,22 @@ struct hdp_threshold_plan {
   bool vec = false;         // lpc == 16 and the block columns split into runs (>= 4) of adjacent time steps
   hdp::DevBuf blk_grp_off, grp_col;  // vec: int32 [n_blocks + 1] offsets, first column of every group of four
   mutable hdp::DevBuf clk;       // HDP_THR_DEBUG=8 phase clocks (-DHDP_DEBUG_ABLATIONS builds only)
+  // time-major input (hdp_thresholds_f32_tm_dev): two series-major staging chunks, a copy stream, fork/join events
+  mutable hdp::DevBuf tm_stage;
+  mutable hipStream_t tm_stream = nullptr;
+  mutable hipEvent_t tm_fork = nullptr, tm_copied[2] = {nullptr, nullptr}, tm_used[2] = {nullptr, nullptr};
+  ~hdp_threshold_plan() {
+    if (tm_fork) (void)hipEventDestroy(tm_fork);
+    for (int i = 0; i < 2; ++i) {
+      if (tm_copied[i]) (void)hipEventDestroy(tm_copied[i]);
+      if (tm_used[i]) (void)hipEventDestroy(tm_used[i]);
+    }
+    if (tm_stream) (void)hipStreamDestroy(tm_stream);
+  }
   // lane-per-column kernel (S <= 100, W <= 16): one lane sorts one column in registers, no cross-lane stage
   bool lane = false;
   int32_t lane_n = 0;            // register slots per column: the kernel's template parameter N >= S
+  size_t lane_lds_bytes = 0;     // dynamic LDS of the lane kernel (its head strips are smaller)
   hdp::DevBuf tixl;              // int32 per block [S][64 * tasks]: byte offset of sample s of local column c
   hdp::DevBuf blk_tixl_off;      // int32 [n_blocks] first element of each block in tixl
   // HDP_THR_* selectors (testing and A/B only; every value gives the same results): read ONCE, when the plan is
@@ -136,6 +149,11 @@ struct hdp_metrics_plan {
   hdp::DevBuf seasons;   // int2 [2][Y]  (north, south)
   mutable hdp::DevBuf bits_scratch;  // split path: exceedance words of two batches of series (double buffer)
   mutable hdp::DevBuf rows_scratch;  // (percentile, definition)-per-lane kernels: [4][P][D][batch][Ypitch] int16
+  mutable hdp::DevBuf tm_stage;      // time-major input: two series-major staging batches
+  // season tables that are not increasing and disjoint (user-supplied): served by the per-series unit kernels
+  bool ordered_seasons = true;
+  hdp::DevBuf ranges64;              // int64 [2][Y][2] north then south, as given (any order, may overlap)
+  std::vector<int64_t> defs_host;    // [D][3]
   // split path: the streaming exceedance kernel of batch b+1 runs on a second stream beside the
   // VALU-bound state-machine kernel of batch b (created on first use, owned by the plan)
   // HDP_METRICS_* selectors (testing and A/B only; every value gives the same results), read once at plan creation
@@ -158,9 +176,16 @@ namespace hdp {
 // kernel launchers (defined in the .hip files)
 int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_t n_cells,
                       double *out_dev, hipStream_t stream);
+// tm_pitch > 0: x_dev is time-major [T][tm_pitch] (element (t, c) at x_dev[t * tm_pitch + c]), else series-major
 int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
                    int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells,
-                   int16_t *out_dev, hipStream_t stream);
+                   int16_t *out_dev, hipStream_t stream, int64_t tm_pitch = 0);
+int launch_metrics_any_ranges(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
+                              int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells, int16_t *out_dev,
+                              hipStream_t stream, int64_t tm_pitch);
+// x_tm_dev time-major [T][pitch]: chunks of cells are transposed on the plan's copy stream beside the kernel
+int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, int64_t pitch, int64_t n_cells,
+                         double *out_dev, hipStream_t stream);
 int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells);
 int launch_table_percentiles(const float *x_dev, int64_t n_cells, int64_t T, const int64_t *win_dev,
                              int64_t n_doy, int64_t B, const QuantileParam *qp_dev,

@@ -1453,11 +1453,13 @@ int64_t metrics_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells, int64
   // of the state-machine kernel runs for about a millisecond, so a launch needs many waves per slot
   // (8192 series per launch cost +20 % in tail effects)
   int64_t batch = std::max<int64_t>(1, (int64_t(4) << 30) / row_bytes);
-  if (const char *env = getenv("HDP_METRICS_BATCH")) batch = std::max<int64_t>(1, atoll(env));
+  if (plan->opt_batch > 0) batch = plan->opt_batch;
   if (n_thr_cells != n_cells && batch < n_cells)
     batch = std::max<int64_t>(n_thr_cells, batch / n_thr_cells * n_thr_cells);
   return std::min<int64_t>(batch, n_cells);
 }
+
+static inline bool one_to_one_pre(int64_t n_thr_cells, int64_t n_cells) { return n_thr_cells == n_cells; }
 
 // streams and events of the split path (created once per plan; also by hdp_metrics_plan_reserve, so that a
 // later hdp_metrics_f32_dev creates nothing)
@@ -1489,10 +1491,85 @@ int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells) {
   return HDP_OK;
 }
 
+
+// ---- season tables that are not increasing and disjoint (user-supplied ranges; the reference's
+// compute_heatwave_metrics, metric.py:304-341, takes any) --------------------------------------------------------
+// The streaming kernels above close seasons in order; such tables go through the unit-level kernels instead, one
+// (percentile, definition) at a time over batches of series: hot days -> index_heatwaves -> season_metrics for the
+// northern and the southern table -> the series' own hemisphere is stored.  Slow (the season kernel is quadratic in
+// the season length) and meant for the small inputs such tables come with.
+__global__ void hot_days_layout_kernel(const float *__restrict__ x, int64_t x_pitch_t, int64_t x_pitch_c, int64_t n,
+                                       int64_t T, const double *__restrict__ thr, int64_t n_thr_cells, int P, int p,
+                                       int n_doy, const uint16_t *__restrict__ doy_map, int64_t c0,
+                                       uint8_t *__restrict__ hot) {
+  const int64_t total = n * T;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t s = i / T, t = i % T;
+    const double th = thr[(((c0 + s) % n_thr_cells) * P + p) * int64_t(n_doy) + doy_map[t]];
+    hot[i] = ((double)x[(c0 + s) * x_pitch_c + t * x_pitch_t] > th) ? 1 : 0;
+  }
+}
+__global__ void pick_hemisphere_kernel(const int64_t *__restrict__ res_n, const int64_t *__restrict__ res_s,
+                                       const uint8_t *__restrict__ is_south, int64_t n, int64_t Y, int64_t c0,
+                                       int64_t n_total, int64_t plane /* P*D*Y*n_total */, int64_t pd_index,
+                                       int16_t *__restrict__ out) {
+  const int64_t total = n * 4 * Y;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t s = i / (4 * Y), r = i % (4 * Y), m = r / Y, y = r % Y;
+    const int64_t v = (is_south[c0 + s] ? res_s : res_n)[i];
+    out[m * plane + (pd_index * Y + y) * n_total + c0 + s] = (int16_t)v;
+  }
+}
+
+static unsigned grid_for(int64_t total, int block);
+
+int launch_metrics_any_ranges(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
+                              int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells, int16_t *out_dev,
+                              hipStream_t stream, int64_t tm_pitch) {
+  const int64_t T = plan->T, Y = plan->Y, P = plan->P, D = plan->D;
+  const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(n_cells, (int64_t(1) << 30) / (T * 8)));
+  DevBuf hot, ids, resn, ress, hwa;
+  HDP_HIP_TRY(hot.alloc(size_t(batch) * T));
+  HDP_HIP_TRY(ids.alloc(size_t(batch) * T * 8));
+  HDP_HIP_TRY(resn.alloc(size_t(batch) * 4 * Y * 8));
+  HDP_HIP_TRY(ress.alloc(size_t(batch) * 4 * Y * 8));
+  HDP_HIP_TRY(hwa.alloc(size_t(batch) * Y * 8));
+  const int64_t pt = tm_pitch > 0 ? tm_pitch : 1, pc = tm_pitch > 0 ? 1 : T;
+  const int64_t plane = P * D * Y * n_cells;
+  for (int64_t c0 = 0; c0 < n_cells; c0 += batch) {
+    const int64_t nb = std::min(batch, n_cells - c0);
+    for (int64_t p = 0; p < P; ++p) {
+      hipLaunchKernelGGL(hot_days_layout_kernel, dim3(grid_for(nb * T, 256)), dim3(256), 0, stream, x_dev, pt, pc, nb, T,
+                         thr_dev, n_thr_cells, (int)P, (int)p, (int)plan->n_doy, plan->doy_map.as<uint16_t>(), c0,
+                         hot.as<uint8_t>());
+      HDP_HIP_TRY(hipGetLastError());
+      for (int64_t d = 0; d < D; ++d) {
+        const int64_t *df = plan->defs_host.data() + 3 * d;
+        int rc = launch_index_heatwaves(hot.as<uint8_t>(), nb, T, df[0], df[1], df[2], ids.as<int64_t>(), stream);
+        if (rc != HDP_OK) return rc;
+        rc = launch_season_metrics(ids.as<int64_t>(), nb, T, plan->ranges64.as<int64_t>(), Y, resn.as<int64_t>(),
+                                   hwa.as<double>(), stream);
+        if (rc != HDP_OK) return rc;
+        rc = launch_season_metrics(ids.as<int64_t>(), nb, T, plan->ranges64.as<int64_t>() + 2 * Y, Y, ress.as<int64_t>(),
+                                   hwa.as<double>(), stream);
+        if (rc != HDP_OK) return rc;
+        hipLaunchKernelGGL(pick_hemisphere_kernel, dim3(grid_for(nb * 4 * Y, 256)), dim3(256), 0, stream,
+                           resn.as<int64_t>(), ress.as<int64_t>(), is_south_dev, nb, Y, c0, n_cells, plane, p * D + d,
+                           out_dev);
+        HDP_HIP_TRY(hipGetLastError());
+      }
+    }
+  }
+  HDP_HIP_TRY(hipStreamSynchronize(stream));  // the scratch buffers are released on return
+  return HDP_OK;
+}
+
 int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
                    int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells, int16_t *out_dev,
-                   hipStream_t stream) {
+                   hipStream_t stream, int64_t tm_pitch) {
   if (n_cells == 0) return HDP_OK;
+  if (!plan->ordered_seasons)  // overlapping / unordered user tables: per-series path, any ranges
+    return launch_metrics_any_ranges(plan, x_dev, thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev, stream, tm_pitch);
   MetDev md;
   md.doy_map = plan->doy_map.as<uint16_t>();
   md.defs = plan->defs.as<int32_t>();
@@ -1524,12 +1601,11 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   //   general           metrics_kernel_general: seasons closed per lane     close/unordered season tables
   // The last three produce rows [4][P][D][series][Ypitch] in a scratch; a transpose brings them to the
   // device layout [4][P][D][Y][series].
-  const bool uniform = plan->uniform_seasons && !getenv("HDP_METRICS_GENERAL");
-  const bool split = uniform && !getenv("HDP_METRICS_FUSED");
-  const bool by_cells = split && !(getenv("HDP_METRICS_CELLS") && atoi(getenv("HDP_METRICS_CELLS")) == 0);
+  const bool uniform = plan->uniform_seasons && !plan->opt_general;
+  const bool split = uniform && !plan->opt_fused;
+  const bool by_cells = split && plan->opt_cells != 0;
   // packed 16-bit state machines (two definitions per register) when the definitions and the record allow
-  const bool pk_ok = by_cells && plan->defs_fit16 && plan->T <= 65535 &&
-                     !(getenv("HDP_METRICS_PACKED") && atoi(getenv("HDP_METRICS_PACKED")) == 0);
+  const bool pk_ok = by_cells && plan->defs_fit16 && plan->T <= 65535 && plan->opt_packed != 0;
   const size_t seas_bytes = uniform ? 0 : ((size_t(2) * md.Y * sizeof(int2) + 15) & ~size_t(15));
   const size_t thr_bytes = split ? 0 : ((size_t(md.np_max) * md.n_doy_pad * 4 + 15) & ~size_t(15));
   const size_t per_wave = thr_bytes + size_t(md.np_max) * (uniform ? kRow : kChunkWords) * 8;
@@ -1547,6 +1623,16 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   const size_t row_bytes = size_t(md.P) * md.words_pad * 8;           // exceedance words of one series
   const size_t rows_bytes = size_t(4) * PD * md.Ypitch * 2;           // row-layout metrics of one series
   int64_t batch = split ? metrics_batch_cells(plan, n_cells, n_thr_cells) : n_cells;
+  // Time-major input [T][tm_pitch] (CMIP order): every batch is transposed into a series-major staging buffer on the
+  // stream its exceedance kernel runs on -- the only kernel that reads the measure -- so the copy of batch b + 1 runs
+  // beside the state machines of batch b.  Smaller batches bound the staging (2 x batch x T x 4 bytes).
+  const bool tm = tm_pitch > 0;
+  HDP_REQUIRE(!tm || split, HDP_EUNSUP, "time-major input needs the split metrics path");
+  if (tm) {
+    int64_t cap = std::max<int64_t>(64, (int64_t(6) << 30) / (int64_t(md.T) * 4));
+    if (!one_to_one_pre(n_thr_cells, n_cells) && cap < n_cells) cap = std::max<int64_t>(n_thr_cells, cap / n_thr_cells * n_thr_cells);
+    batch = std::min(batch, cap);
+  }
   if (!by_cells) {
     int64_t cap = std::max<int64_t>(1, (int64_t(1) << 30) / (int64_t)rows_bytes);
     if (!one_to_one && cap < n_cells) cap = std::max<int64_t>(n_thr_cells, cap / n_thr_cells * n_thr_cells);
@@ -1565,10 +1651,17 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     const int rc = grow(plan->bits_scratch, 2 * size_t(batch) * row_bytes, "exceedance");
     if (rc != HDP_OK) return rc;
   }
+  if (tm) {
+    const int rc = grow(plan->tm_stage, 2 * size_t(batch) * md.T * 4, "time-major staging");
+    if (rc != HDP_OK) return rc;
+  }
   if (!by_cells) {
     const int rc = grow(plan->rows_scratch, size_t(batch) * rows_bytes, "metrics row");
     if (rc != HDP_OK) return rc;
   }
+  // a failed allocation leaves the buffer empty (DevBuf::alloc): never launch on a null scratch
+  HDP_REQUIRE(!split || plan->bits_scratch.p, HDP_ENOMEM, "exceedance scratch is not allocated");
+  HDP_REQUIRE(by_cells || plan->rows_scratch.p, HDP_ENOMEM, "metrics row scratch is not allocated");
   md.bits_g = plan->bits_scratch.as<unsigned long long>();
   const size_t lds_a = (size_t((md.P + kQB - 1) / kQB * kQB) * md.n_doy * 4 + 15) & ~size_t(15);
   const bool short_record = ((md.T + 63) >> 6) <= 64;  // at most two 32-word chunks: use 16-word chunks, all four waves
@@ -1581,7 +1674,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   if (!by_cells)
     HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_rows),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const bool overlap = split && !(getenv("HDP_METRICS_OVERLAP") && atoi(getenv("HDP_METRICS_OVERLAP")) == 0);
+  const bool overlap = split && plan->opt_overlap != 0;
   if (overlap) {
     const int rc = ensure_plan_streams(plan);
     if (rc != HDP_OK) return rc;
@@ -1605,13 +1698,17 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
                 "shared thresholds need batches aligned to the number of threshold cells");
     const double *thr_b = one_to_one ? thr_dev + c0 * int64_t(md.n_doy) * md.P : thr_dev;
     const int64_t ntc_b = one_to_one ? nc : n_thr_cells;
-    const float *x_b = x_dev + c0 * int64_t(md.T);
+    const float *x_b = tm ? plan->tm_stage.as<float>() + size_t(half) * size_t(batch) * md.T : x_dev + c0 * int64_t(md.T);
     MetDev mb = md;
     mb.bits_g = md.bits_g + size_t(half) * size_t(batch) * (row_bytes / 8);
     hipStream_t sm = (overlap && half) ? plan->aux_stream2 : stream;  // stream of this batch's state machine
     if (split) {
       // this half of the scratch is free once the state machine of batch b - 2 has read it
       if (overlap && b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_state[half], 0));
+      if (tm) {  // staging half `half` was last read by the exceedance kernel of batch b - 2, earlier on this stream
+        const int rc = launch_transpose(x_dev + c0, tm_pitch, md.T, nc, const_cast<float *>(x_b), sx);
+        if (rc != HDP_OK) return rc;
+      }
       if (short_record)
         hipLaunchKernelGGL(exceed_kernel<16>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
       else

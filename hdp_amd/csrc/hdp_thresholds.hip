@@ -386,7 +386,8 @@ __device__ __forceinline__ QuantileParam ldk(const QuantileParam *p) {
   return q;
 }
 
-template <bool TOP>
+// RAW: best / prev are float bit patterns (the lane-per-column kernel's image), not order-preserving keys
+template <bool TOP, bool RAW = false>
 __device__ __forceinline__ void emit_targets(const ThrDev &pd, const int2 *tgt, int nt, int &k, int &next_rank,
                                              int step, int best, int prev, const RowFlags &rf, bool store,
                                              double *orow) {
@@ -394,9 +395,10 @@ __device__ __forceinline__ void emit_targets(const ThrDev &pd, const int2 *tgt, 
   int2 t = ldk(&tgt[kk]);
   do {
     const int p = t.y & 0xffff, kind = t.y >> 16;
-    float lo = key_f32(best), hi = key_f32(best);
-    if (kind == E_TOP_PAIR) hi = key_f32(prev);
-    if (kind == E_BOT_PAIR) lo = key_f32(prev);
+    const float fb = RAW ? __int_as_float(best) : key_f32(best), fp = RAW ? __int_as_float(prev) : key_f32(prev);
+    float lo = fb, hi = fb;
+    if (kind == E_TOP_PAIR) hi = fp;
+    if (kind == E_BOT_PAIR) lo = fp;
     const QuantileParam qp = ldk(&pd.qp[p]);
     // percentile-major output: consecutive lanes (rows) write consecutive doubles
     if (store) orow[size_t(p) * pd.n_doy] = finish_quantile(qp, lo, hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
@@ -736,6 +738,140 @@ __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf
     merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
     merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
   }
+}
+
+
+// ---- lean heads for the lane-per-column kernel ----------------------------------------------------------------
+// One wave issues about one instruction per 4.6 cycles whatever the instruction (tools/ubench), so a merging
+// wave's step time is its instruction count plus whatever LDS latency it cannot cover -- the SIMD itself is mostly
+// idle under it.  This form of the merge therefore spends as few instructions per step as the data layout allows:
+//  * the image holds the samples' RAW float bits (NaNs scrubbed): used as the high word of a double they order like
+//    the floats themselves (sign-magnitude both; the exponent field of the double is all ones only for NaN
+//    patterns, which never occur, and the sentinels 0x7fe00000 / 0xffe00000 lie beyond +-inf and are finite
+//    doubles), so a head is (float bits, payload) with NO key transformation -- pk_make is gone;
+//  * payload = byte offset of the key in the image | group: next key at (payload & ~3) + 4, new payload = payload + 4;
+//    among equal keys the payload orders positive values one way and negative values the other -- either is a
+//    total order, which is all the merge needs (equal keys are equal values);
+//  * a group's strip keeps only its 2nd..4th head (the top is the cached top being popped): 24 bytes per (group,
+//    row) in two arrays with compile-time pitch (128 rows), read and written as b128 + b64;
+//  * software-pipelined like merge_row_pl: the next step's reads are issued as soon as the next winner is known.
+constexpr int kLeanRows = 128;                       // strip pitch (rows per block <= 128)
+constexpr uint32_t kRawMax = 0x7fe00000u;            // above +inf (0x7f800000), finite as the high word of a double
+constexpr uint32_t kRawMin = 0xffe00000u;            // below -inf (0xff800000)
+template <int NG>
+constexpr size_t lean_strip_bytes() { return size_t(NG) * kLeanRows * 24; }
+
+template <bool TOP, int NG>
+__device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
+                                               const uint16_t *cl, int r, const RowFlags &rf, double *orow) {
+  static_assert(NG >= 1 && NG <= 4, "group id is two payload bits");
+  const int steps = TOP ? pd.steps_top : pd.steps_bot;
+  const int nt = TOP ? pd.nt_top : pd.nt_bot;
+  const int2 *tgt = TOP ? pd.tgt_top : pd.tgt_bot;
+  if (steps == 0) return;
+  auto better = [](double a, double b) { return TOP ? pk_max(a, b) : pk_min(a, b); };
+  auto worse = [](double a, double b) { return TOP ? pk_min(a, b) : pk_max(a, b); };
+  auto head = [](uint32_t bits, uint32_t pay) { return __hiloint2double(int(bits), int(pay)); };
+  // strips: A[g][row] = (2nd, 3rd) 16 bytes, B[g][row] = 4th 8 bytes
+  unsigned char *const sA = strips + size_t(r) * 16;
+  unsigned char *const sB = strips + size_t(NG) * kLeanRows * 16 + size_t(r) * 8;
+  double m[NG];
+  {
+    // column heads: first (TOP) or last (bottom) sample of each window column; slots past W read a losing sentinel
+    const uint32_t dummy = TOP ? uint32_t(1 + pd.S) * 4u : 0u;  // column 0's trailing / leading sentinel
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      double hd[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 4 * g + i;
+        const uint32_t pos = (j < pd.W) ? uint32_t(int(cl[j]) * pd.S_pad + (TOP ? 1 : pd.S)) * 4u : dummy;
+        hd[i] = head(*reinterpret_cast<const uint32_t *>(image + pos), pos | uint32_t(g));
+      }
+      sort_best_first<TOP, 4>(hd);
+      *reinterpret_cast<double2 *>(sA + g * (kLeanRows * 16)) = make_double2(hd[1], hd[2]);
+      *reinterpret_cast<double *>(sB + g * (kLeanRows * 8)) = hd[3];
+      m[g] = hd[0];
+    }
+    sort_best_first<TOP, NG>(m);
+  }
+  int k = 0;
+  int next_rank = nt > 0 ? ldk(&tgt[0]).x : -1;
+  double prev = head(TOP ? kRawMin : kRawMax, 0);
+
+  uint32_t nk;      // next key (float bits) of the popped column
+  double2 h12;      // popped group's 2nd and 3rd head
+  double h3;        // ... and 4th
+  uint32_t lo_cur;  // payload of the popped head
+  uint32_t g_cur;
+  auto issue = [&](double top) {
+    lo_cur = uint32_t(__double2loint(top));
+    g_cur = lo_cur & 3u;
+    nk = *reinterpret_cast<const uint32_t *>(image + (lo_cur & ~3u) + (TOP ? 4 : -4));
+    h12 = *reinterpret_cast<const double2 *>(sA + g_cur * (kLeanRows * 16));
+    h3 = *reinterpret_cast<const double *>(sB + g_cur * (kLeanRows * 8));
+  };
+  double b1 = 0.0, b2 = 0.0, b3 = 0.0;  // previous step's group after insertion (what its write-back stores)
+  uint32_t g_prev = 4;
+  issue(m[0]);
+  auto do_step = [&]() {
+    prev = m[0];
+    const uint32_t g = g_cur;
+    const bool same = g == g_prev;
+    const double fresh = head(nk, lo_cur + (TOP ? 4u : uint32_t(-4)));
+    const double h1 = same ? b1 : h12.x;
+    const double t0 = better(fresh, h1);  // the group's new top
+    double m0n = t0;
+    if constexpr (NG >= 2) m0n = better(t0, m[1]);
+    const double h2 = same ? b2 : h12.y, h3v = same ? b3 : h3;
+    __builtin_amdgcn_sched_barrier(0);
+    issue(m0n);  // next step's reads first
+    __builtin_amdgcn_sched_barrier(0);
+    const double w1 = worse(fresh, h1);
+    b1 = better(w1, h2);
+    const double w2 = worse(w1, h2);
+    b2 = better(w2, h3v);
+    b3 = worse(w2, h3v);
+    *reinterpret_cast<double2 *>(sA + g * (kLeanRows * 16)) = make_double2(b1, b2);
+    *reinterpret_cast<double *>(sB + g * (kLeanRows * 8)) = b3;
+    g_prev = g;
+    m[0] = m0n;
+    if constexpr (NG >= 2) {
+      double w = worse(t0, m[1]);
+#pragma unroll
+      for (int i = 1; i + 1 < NG; ++i) {
+        const double nb = better(w, m[i + 1]);
+        w = worse(w, m[i + 1]);
+        m[i] = nb;
+      }
+      m[NG - 1] = w;
+    }
+  };
+  int step = 0;
+  while (true) {
+    const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
+    for (; step < stop; ++step) do_step();
+    if (step >= steps) break;
+    emit_targets<TOP, true>(pd, tgt, nt, k, next_rank, step, __double2hiint(m[0]), __double2hiint(prev), rf, true, orow);
+    next_rank = __builtin_amdgcn_readfirstlane(next_rank);
+  }
+}
+
+template <int NG>
+__device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
+                                                const uint32_t *flags, const uint16_t *cl, int r, double *orow) {
+  RowFlags rf{0, 0};
+  uint32_t nan_or = 0;
+#pragma unroll
+  for (int j = 0; j < 4 * NG; ++j) {
+    const uint32_t f = (j < pd.W) ? flags[cl[j]] : 0u;
+    nan_or |= f;
+    rf.n_pos += (f >> 15) & 0x7fff;
+    rf.n_neg += f & 0x7fff;
+  }
+  if (nan_or >> 31) rf.n_pos = -1;
+  merge_row_lean<true, NG>(pd, image, strips, cl, r, rf, orow);
+  merge_row_lean<false, NG>(pd, image, strips, cl, r, rf, orow);
 }
 
 // ---- rank selection (many samples per column) ---------------------------------------------------
@@ -1269,12 +1405,13 @@ constexpr int ilog2_ceil(int n) {
   while ((1 << t) < n) ++t;
   return t;
 }
-// compare-exchange of two order-preserving int keys, larger to `a`.  asm volatile: the statements keep their program
+// compare-exchange of two samples (float bits), larger to `a`.  asm volatile: the statements keep their program
 // order, so the N keys plus one temporary are all that is ever live -- left to itself the scheduler stretches the
 // live ranges of a 1000-comparator network until it spills (N = 100: 256 VGPRs and 417 spills, measured).
+// The operands are NaN-free float bit patterns; denormals are preserved (FLOAT_DENORM_MODE_32 = 3 in these kernels).
 __device__ __forceinline__ void ce_key(int &a, int &b) {
   int hi;
-  asm volatile("v_max_i32 %0, %1, %2\n\tv_min_i32 %1, %1, %2" : "=&v"(hi), "+v"(b) : "v"(a));
+  asm volatile("v_max_f32 %0, %1, %2\n\tv_min_f32 %1, %1, %2" : "=&v"(hi), "+v"(b) : "v"(a));
   a = hi;
 }
 // The passes (p, r, d) of merge exchange for N keys, as compile-time constants: pass k compares v[i] with v[i + d]
@@ -1374,10 +1511,8 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev 
   uint32_t *flags0 = reinterpret_cast<uint32_t *>(smem + off);  // census words, double-buffered by block parity
   const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
   off += 2 * size_t(flags_pitch) * 4;
-  float *hbuf = reinterpret_cast<float *>(smem + off);
-  off += size_t(pd.Wp) * pd.RP * 4;
-  uint32_t *posb = reinterpret_cast<uint32_t *>(smem + off);
-  off += size_t(pd.Wp) * pd.RP * 4;
+  unsigned char *strips = smem + off;  // merge heads: 2nd..4th of every (group, row), see merge_row_lean
+  off += lean_strip_bytes<NG>();
   uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][W] local columns of this block's windows
 
   const int nb = pd.n_blocks;
@@ -1428,7 +1563,7 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev 
   // (up to 100 registers) were live across the merging waves' code as well and the kernel spilled.
   if (producer) {
     for (int64_t s = 0; s <= n_items; ++s) {
-      int v[TPW][N];  // sorted keys of this wave's tasks
+      int v[TPW][N];  // sorted samples (float bits) of this wave's tasks
       uint32_t *flags_p = flags0 + int(s & 1) * flags_pitch;  // census of block s (double-buffered by parity)
       unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
       const bool clocked = HDP_DBG(pd, 32) && lane == 0 && pw == 0;
@@ -1489,14 +1624,13 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev 
             }
             if (lc < ncols)
               flags_p[lc] = ((cnt >> 20) ? 0x80000000u : 0u) | (((cnt >> 10) & 0x3ffu) << 15) | (cnt & 0x3ffu);
-            // order-preserving keys (what the LDS image holds); slots past S get the trailing sentinel's key and
-            // sort to the tail (wave-uniform select)
+            // the image holds the samples themselves; slots past S become -inf and sort to the tail (wave-uniform
+            // select; they are written onto the trailing sentinel's slot, which is stored last)
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-              const int key = f32_key(__int_as_float(v[k][i]));
-              v[k][i] = (i >= lane_first_pad_slot(N) && i >= S_rt) ? kKeyMin : key;
-            }
+            for (int i = lane_first_pad_slot(N); i < N; ++i) v[k][i] = (i >= S_rt) ? int(0xff800000u) : v[k][i];
+#if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 2))
             sort_lane_desc<N>(v[k]);
+#endif
           }
         }
       }
@@ -1519,8 +1653,8 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev 
               if (i < lane_first_pad_slot(N)) col[i] = __int_as_float(v[k][i]);
               else col[min(i, S_rt)] = __int_as_float(v[k][i]);
             }
-            col[-1] = __int_as_float(kKeyMax);    // below every ascending walk
-            col[S_rt] = __int_as_float(kKeyMin);  // below every descending walk
+            col[-1] = __uint_as_float(kRawMax);    // loses every ascending walk
+            col[S_rt] = __uint_as_float(kRawMin);  // loses every descending walk
           }
         }
       }
@@ -1544,7 +1678,9 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev 
         const int row = row0 + mrow;
         const uint16_t *cl = cl_lds + mrow * pd.W;
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
-        merge_both<NG, true>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow);
+#if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 1))
+        merge_both_lean<NG>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips, flags_m, cl, mrow, orow);
+#endif
       }
       if (clocked) c1 = __builtin_readcyclecounter();
       __syncthreads();  // merge of block s - 1 done: image free
@@ -1787,7 +1923,7 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
     snprintf(buf, sizeof buf,
              "thresholds_lane_kernel<N=%d,NG=%d> (one lane per column: register merge-exchange sort; %d merging waves; "
              "%d rows x %d blocks, %zu B LDS)",
-             plan->lane_n, plan->Wp >> 2, plan->n_merge, plan->rows_per_block, plan->n_blocks, plan->lds_bytes);
+             plan->lane_n, plan->Wp >> 2, plan->n_merge, plan->rows_per_block, plan->n_blocks, plan->lane_lds_bytes);
   else if (v.pipe)
     snprintf(buf, sizeof buf,
              "thresholds_pipe_kernel<LPC=%d,%s,NG=%d> (register sort producers + %d merging waves; %d rows x %d blocks, "
@@ -1864,14 +2000,14 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.select = var.select;
   if (var.lane) {
     switch (plan->lane_n) {
-      case 8: return launch_thr_lane<8>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 16: return launch_thr_lane<16>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 24: return launch_thr_lane<24>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 32: return launch_thr_lane<32>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 48: return launch_thr_lane<48>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 64: return launch_thr_lane<64>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 80: return launch_thr_lane<80>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 100: return launch_thr_lane<100>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 8: return launch_thr_lane<8>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 16: return launch_thr_lane<16>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 24: return launch_thr_lane<24>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 32: return launch_thr_lane<32>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 48: return launch_thr_lane<48>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 64: return launch_thr_lane<64>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 80: return launch_thr_lane<80>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 100: return launch_thr_lane<100>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
       default: return set_error(HDP_EUNSUP, "lane-per-column kernel: no instantiation for %d slots", plan->lane_n);
     }
   }
@@ -1899,6 +2035,49 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
     default: return set_error(HDP_EUNSUP, "samples per day-of-year S=%lld not supported (max 2048)",
                               (long long)plan->S);
   }
+}
+
+// Time-major input [T][pitch] (CMIP order): chunks of cells are transposed into series-major staging buffers on the
+// plan's copy stream while the kernel works on the previous chunk (the thresholds kernels are latency-bound and leave
+// HBM mostly idle, so the copy hides behind them).  Two staging chunks, fork/join by events on the caller's stream.
+int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, int64_t pitch, int64_t n_cells,
+                         double *out_dev, hipStream_t stream) {
+  if (n_cells == 0) return HDP_OK;
+  const int64_t T = plan->T;
+  const int64_t chunk = std::min<int64_t>(n_cells, std::max<int64_t>(256, (int64_t(5) << 30) / (T * 4)));
+  if (!plan->tm_stream) {
+    HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->tm_stream, hipStreamNonBlocking));
+    HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_fork, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+      HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_copied[i], hipEventDisableTiming));
+      HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_used[i], hipEventDisableTiming));
+    }
+  }
+  const size_t need = 2 * size_t(chunk) * T * 4;
+  if (plan->tm_stage.bytes < need) {
+    HDP_HIP_TRY(hipStreamSynchronize(stream));
+    HDP_HIP_TRY(hipStreamSynchronize(plan->tm_stream));
+    const hipError_t e = plan->tm_stage.alloc(need);
+    if (e != hipSuccess)
+      return set_error(HDP_ENOMEM, "allocating %zu bytes of time-major staging failed: %s", need, hipGetErrorString(e));
+  }
+  HDP_HIP_TRY(hipEventRecord(plan->tm_fork, stream));
+  HDP_HIP_TRY(hipStreamWaitEvent(plan->tm_stream, plan->tm_fork, 0));
+  int64_t b = 0;
+  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk, ++b) {
+    const int64_t nc = std::min(chunk, n_cells - c0);
+    const int half = int(b & 1);
+    float *stage = plan->tm_stage.as<float>() + size_t(half) * size_t(chunk) * T;
+    if (b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(plan->tm_stream, plan->tm_used[half], 0));
+    int rc = launch_transpose(x_tm_dev + c0, pitch, T, nc, stage, plan->tm_stream);
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipEventRecord(plan->tm_copied[half], plan->tm_stream));
+    HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->tm_copied[half], 0));
+    rc = launch_thresholds(plan, stage, nc, out_dev + c0 * plan->n_doy * plan->P, stream);
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipEventRecord(plan->tm_used[half], stream));
+  }
+  return HDP_OK;
 }
 
 int launch_table_percentiles(const float *x_dev, int64_t n_cells, int64_t T, const int64_t *win_dev,
@@ -2122,6 +2301,16 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   }
   pl->lane = lane;
   pl->lane_n = lane_n;
+  if (lane) {
+    // the lane kernel's own LDS layout: image, census (x2), lean head strips (24 bytes per group and row, pitch
+    // kLeanRows), window column lists
+    size_t b = (size_t(cm) * spad * 4 + 15) & ~size_t(15);
+    b += 2 * ((size_t(cm) * 4 + 15) & ~size_t(15));
+    b += size_t(ngw) * hdp::kLeanRows * 24;
+    b += (size_t(rows) * W * 2 + 15) & ~size_t(15);
+    pl->lane_lds_bytes = b;
+    if (b > kMaxLds || rows > hdp::kLeanRows) pl->lane = false;
+  }
   if (lpc && !pipe && !lane && !rows_forced) {
     for (int r = rows - 1; r >= std::max(1, rows / 2); --r) {
       const int nb = int((n_doy + r - 1) / r);

@@ -2,14 +2,31 @@
 
 Every series is independent in both passes (reference docs/testing.rst:21; gufunc core
 dims threshold.py:57, metric.py:364), so rank r owns the contiguous cell range
-[r*ceil(n/W), (r+1)*ceil(n/W)) and no collective runs during compute.  The only exchange
-is the all-gather that reassembles the (int16) metrics, and optionally the thresholds,
-on every rank -- RCCL over xGMI when the tensors live on the GPU (torch.distributed
-backend "nccl"), gloo in the CPU tests.
+[r*ceil(n/W), (r+1)*ceil(n/W)) and no collective runs during compute -- the split the
+reference expresses as dask chunks (threshold.py:161-169, metric.py:444-452).  The only
+exchange is the all-gather that reassembles the (int16/int64) metrics, and the thresholds,
+on every rank.
+
+Transport, in order of preference:
+  * the library's own RCCL communicator (``hdp_comm_*`` / ``hdp_allgather_dev`` in
+    include/hdp_hip.h: ncclAllGather over xGMI, no torch involved) once ``comm_init_rank``
+    or ``init_from_env`` has run;
+  * ``torch.distributed`` if the caller initialised a process group (backend "nccl" is RCCL
+    on ROCm; "gloo" in the CPU tests);
+  * none for a single process.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import socket
+import time
+
 import numpy as np
+
+from . import _lib
+
+COMM_ID_BYTES = 128   # HDP_COMM_ID_BYTES (sizeof(ncclUniqueId))
 
 
 def shard_size(n_cells: int, world: int) -> int:
@@ -31,17 +48,140 @@ def pad_cells(local: np.ndarray, n_pad: int, axis: int) -> np.ndarray:
     return np.pad(local, widths)
 
 
-def allgather_cells(local, n_cells: int, axis: int, group=None, device=None):
+# ---- the library's RCCL communicator (C ABI; no torch) ---------------------------------------
+
+def comm_unique_id() -> bytes:
+    """Rank 0: the 128 bytes every other rank needs for comm_init_rank (ship them by any channel)."""
+    lib = _lib.ensure_device()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _lib.check(lib.hdp_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init_rank(ident: bytes, rank: int, world: int) -> None:
+    """Collective: every rank calls this with rank 0's id (ncclCommInitRank)."""
+    lib = _lib.ensure_device()
+    if len(ident) != COMM_ID_BYTES:
+        raise ValueError(f"communicator id must be {COMM_ID_BYTES} bytes")
+    _lib.check(lib.hdp_comm_init_rank(C.create_string_buffer(bytes(ident), COMM_ID_BYTES), int(rank), int(world)))
+
+
+def comm_destroy() -> None:
+    _lib.load().hdp_comm_destroy()
+
+
+def comm_world() -> int:
+    return int(_lib.load().hdp_comm_world())
+
+
+def comm_rank() -> int:
+    return int(_lib.load().hdp_comm_rank())
+
+
+def comm_ready() -> bool:
+    return comm_world() > 0
+
+
+def init_from_env(port_offset: int = 29, timeout: float = 120.0):
+    """Torch-free start-up under any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
+    MASTER_PORT (torchrun does): rank 0 serves the RCCL unique id on MASTER_PORT + port_offset, the other
+    ranks fetch it, then every rank joins the communicator.  Returns (rank, world)."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    _lib.ensure_device(int(os.environ.get("LOCAL_RANK", "0")))
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset
+    if rank == 0:
+        ident = comm_unique_id()
+        if world > 1:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _peer = srv.accept()
+                conn.sendall(ident)
+                conn.close()
+            srv.close()
+    else:
+        deadline = time.time() + timeout
+        ident = b""
+        while True:
+            try:
+                with socket.create_connection((addr, port), timeout=5.0) as c:
+                    while len(ident) < COMM_ID_BYTES:
+                        chunk = c.recv(COMM_ID_BYTES - len(ident))
+                        if not chunk:
+                            break
+                        ident += chunk
+                if len(ident) == COMM_ID_BYTES:
+                    break
+                ident = b""
+            except OSError:
+                pass
+            if time.time() > deadline:
+                raise TimeoutError(f"rank {rank}: no communicator id from {addr}:{port}")
+            time.sleep(0.2)
+    comm_init_rank(ident, rank, world)
+    return rank, world
+
+
+def _allgather_bytes_rccl(local: np.ndarray) -> np.ndarray:
+    """local: C-contiguous array, equal size on every rank -> [world, *local.shape] through hdp_allgather_dev."""
+    lib = _lib.ensure_device()
+    world = comm_world()
+    nbytes = local.nbytes
+    out = np.empty((world,) + local.shape, dtype=local.dtype)
+    if nbytes == 0:
+        return out
+    send, recv = lib.hdp_dev_alloc(nbytes), lib.hdp_dev_alloc(nbytes * world)
+    if not send or not recv:
+        _lib.check(-4)
+    try:
+        _lib.check(lib.hdp_memcpy_h2d(send, local.ctypes.data_as(C.c_void_p), nbytes))
+        _lib.check(lib.hdp_allgather_dev(send, nbytes, recv, None))
+        _lib.check(lib.hdp_memcpy_d2h(out.ctypes.data_as(C.c_void_p), recv, nbytes * world))
+    finally:
+        lib.hdp_dev_free(send)
+        lib.hdp_dev_free(recv)
+    return out
+
+
+def current(shard=None):
+    """(rank, world) of this process: an explicit ``shard=(rank, world)``, else the library communicator, else an
+    initialised torch.distributed group, else (0, 1)."""
+    if shard is not None and shard != "auto":
+        rank, world = shard
+        return int(rank), int(world)
+    if comm_ready():
+        return comm_rank(), comm_world()
+    try:
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            return tdist.get_rank(), tdist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def allgather_cells(local, n_cells: int, axis: int, group=None, device=None, world=None):
     """All-gather per-rank results along the cell axis and strip the padding.
 
     `local` is this rank's array (numpy, or a torch tensor already on the right device)
     whose `axis` has shard_size(n_cells, world) entries (pad with pad_cells).  Returns the
     reassembled array with n_cells entries along `axis`, same type as the input."""
+    is_np = isinstance(local, np.ndarray)
+    if is_np and comm_ready() and group is None:
+        t = np.ascontiguousarray(np.moveaxis(local, axis, 0))          # cell axis first: shards concatenate
+        g = _allgather_bytes_rccl(t)                                   # [world, shard, ...]
+        g = g.reshape((-1,) + t.shape[1:])[:n_cells]
+        return np.moveaxis(g, 0, axis)
+    if world == 1:
+        return local
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    is_np = isinstance(local, np.ndarray)
     t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local.contiguous()
     if device is not None:
         t = t.to(device)
@@ -52,3 +192,15 @@ def allgather_cells(local, n_cells: int, axis: int, group=None, device=None):
     dist.all_gather_into_tensor(out.view(torch.uint8).reshape(-1), t.view(torch.uint8).reshape(-1), group=group)
     out = out[:n_cells].movedim(0, axis)
     return out.cpu().numpy() if is_np else out
+
+
+def sharded_over_cells(fn, n_cells: int, axis: int, shard):
+    """Run ``fn(lo, hi)`` on this rank's cell range and all-gather the results along ``axis`` (the output's cell
+    axis): what the ``shard=`` argument of the hdp_amd.threshold / hdp_amd.metric adapters does."""
+    rank, world = current(shard)
+    if world == 1:
+        return fn(0, n_cells)
+    lo, hi = shard_bounds(n_cells, world, rank)
+    local = fn(lo, hi)
+    local = pad_cells(np.asarray(local), shard_size(n_cells, world), axis)
+    return allgather_cells(local, n_cells, axis, world=world)

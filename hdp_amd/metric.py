@@ -17,6 +17,7 @@ from pathlib import Path
 import numpy as np
 
 from . import core
+from . import dist as hdist
 from . import io as hio
 from ._xr import backend, jan1_stamps
 from .calendar import build_doy_map, get_range_indices, hemisphere_season_tables  # noqa: F401
@@ -48,17 +49,23 @@ def compute_heatwave_metrics(measure, threshold, doy_map, min_duration, max_brea
 
 
 def compute_individual_metrics(measure, threshold, hw_definitions, include_threshold: bool = True,
-                               check_variables: bool = True):
+                               check_variables: bool = True, shard=None):
     """HWF/HWN/HWD/HWA for one (measure, threshold) pair (metric.py:372-506).
 
     Output variables are int64 with dims (percentile, definition, <non-time dims of the
-    measure in order>, time) where time holds one Jan-1 stamp per season year."""
+    measure in order>, time) where time holds one Jan-1 stamp per season year.
+
+    ``shard`` (not in the reference, whose split over cells is the dask graph of :444-452): ``(rank, world)`` or
+    ``"auto"`` -- this process computes the metrics of its contiguous range of grid cells only (all members of a cell
+    stay on one GPU, with that cell's thresholds) and the ranks' results are all-gathered (hdp_amd.dist: RCCL over
+    xGMI through the library's communicator), so every rank returns the complete Dataset."""
     blocks = hio.block_slices(measure, skip=("time", "member"))
     if blocks is not None and blocks[0] in threshold.dims:
         # lazily chunked measure: one block at a time with the matching slice of the thresholds (metric.py:444)
         dim, edges = blocks
         parts = [compute_individual_metrics(measure.isel(**{dim: slice(a, b)}), threshold.isel(**{dim: slice(a, b)}),
-                                            hw_definitions, include_threshold, check_variables) for a, b in edges]
+                                            hw_definitions, include_threshold, check_variables, shard)
+                 for a, b in edges]
         return hio.concat_dim(parts, dim)
     xr = backend()
     times = np.asarray(measure.coords["time"].values)
@@ -101,8 +108,22 @@ def compute_individual_metrics(measure, threshold, hw_definitions, include_thres
     is_south = np.broadcast_to(lat_b, shape_cells).reshape(-1).astype(np.uint8)
 
     # int64 planes [metric][P][D][series][Y] (int, as test_workflow.py:57), widened and regrouped on the device
-    planes = core.compute_heatwave_metric_planes(x2d, thr3, doy_map, hw_definitions, north, south, is_south)
     D, Y = len(hw_definitions), north.shape[0]
+    if shard is None:
+        planes = core.compute_heatwave_metric_planes(x2d, thr3, doy_map, hw_definitions, north, south, is_south)
+    else:
+        n_thr = thr3.shape[0]
+        n_mem = x2d.shape[0] // n_thr          # series are member-major: [member][cell]
+        x3 = x2d.reshape(n_mem, n_thr, -1)
+        south2 = is_south.reshape(n_mem, n_thr)
+
+        def local(lo, hi):   # -> [4, P, D, member, cells of this rank, Y]
+            pl = core.compute_heatwave_metric_planes(np.ascontiguousarray(x3[:, lo:hi]).reshape(n_mem * (hi - lo), -1),
+                                                     thr3[lo:hi], doy_map, hw_definitions, north, south,
+                                                     np.ascontiguousarray(south2[:, lo:hi]).reshape(-1))
+            return pl.reshape(4, P, D, n_mem, hi - lo, Y)
+
+        planes = hdist.sharded_over_cells(local, n_thr, 4, shard)
     planes = planes.reshape((4, P, D) + tuple(proc_shape) + (Y,))
     # back to the measure's own dim order (a view; only the member dim ever moves)
     src = ["metric", "percentile", "definition"] + proc_dims + ["year"]
@@ -144,9 +165,10 @@ def compute_individual_metrics(measure, threshold, hw_definitions, include_thres
 
 
 def compute_group_metrics(measures, thresholds, hw_definitions, include_threshold: bool = False,
-                          check_variables: bool = True):
+                          check_variables: bool = True, shard=None):
     """Every (measure, threshold) pair with matching ``baseline_variable``; variables are
-    renamed ``{measure}.{threshold}.{metric}`` and merged (metric.py:509-523)."""
+    renamed ``{measure}.{threshold}.{metric}`` and merged (metric.py:509-523).
+    ``shard``: see compute_individual_metrics."""
     xr = backend()
     metric_sets = []
     for measure_name in list(measures.keys()):
@@ -155,7 +177,7 @@ def compute_group_metrics(measures, thresholds, hw_definitions, include_threshol
             threshold = thresholds[threshold_name]
             if threshold.attrs["baseline_variable"] == measure.attrs["baseline_variable"]:
                 hw = compute_individual_metrics(measure, threshold, hw_definitions, include_threshold,
-                                                check_variables)
+                                                check_variables, shard)
                 metric_sets.append(hw.rename({n: f"{measure_name}.{threshold_name}.{n}" for n in list(hw.keys())}))
     aggr = xr.merge(metric_sets)
     aggr.attrs["variable_naming_desc"] = "(heat measure).(threshold used).(heatwave metric)"

@@ -20,6 +20,7 @@ from pathlib import Path
 import numpy as np
 
 from . import core
+from . import dist as hdist
 from . import io as hio
 from ._xr import backend
 from .calendar import datetimes_to_windows, window_columns  # noqa: F401
@@ -36,17 +37,21 @@ def _series_matrix(values, dims, time_dim="time"):
 
 
 def compute_threshold(baseline_data, percentiles, no_season: bool = False, rolling_window_size: int = 7,
-                      fixed_value: float = None):
+                      fixed_value: float = None, shard=None):
     """Percentile thresholds per grid cell and day of year (threshold.py:96-204).
 
     ``rolling_window_size`` is a radius: the window is ``2*rolling_window_size + 1`` days
     (threshold.py:41).  ``no_season`` and ``fixed_value`` are recorded in attrs only, as
-    in the reference (:182-184)."""
+    in the reference (:182-184).
+
+    ``shard`` (not in the reference, whose split over cells is the dask graph of :161-169): ``(rank, world)`` or
+    ``"auto"`` -- this process computes only its contiguous range of grid cells on its GPU and the thresholds of
+    all ranks are all-gathered (hdp_amd.dist), so every rank returns the complete Dataset."""
     blocks = hio.block_slices(baseline_data, skip=("time", "member"))
     if blocks is not None:   # lazily chunked input: one block at a time, as the reference's map_blocks does
         dim, edges = blocks
         parts = [compute_threshold(baseline_data.isel(**{dim: slice(a, b)}), percentiles, no_season,
-                                   rolling_window_size, fixed_value) for a, b in edges]
+                                   rolling_window_size, fixed_value, shard) for a, b in edges]
         return hio.concat_dim(parts, dim)
     xr = backend()
     dims = list(baseline_data.dims)
@@ -65,7 +70,11 @@ def compute_threshold(baseline_data, percentiles, no_season: bool = False, rolli
 
     time_index, cols = window_columns(times, rolling_window_size)
     x2d, other_dims, other_shape = _series_matrix(values, dims)
-    thr = core.compute_percentiles(x2d, time_index, cols, percentiles)
+    if shard is None:
+        thr = core.compute_percentiles(x2d, time_index, cols, percentiles)
+    else:
+        thr = hdist.sharded_over_cells(lambda lo, hi: core.compute_percentiles(x2d[lo:hi], time_index, cols, percentiles),
+                                       x2d.shape[0], 0, shard)
     n_doy = time_index.shape[0]
     thr = thr.reshape(tuple(other_shape) + (n_doy, percentiles.size))
 
@@ -104,10 +113,11 @@ def compute_threshold(baseline_data, percentiles, no_season: bool = False, rolli
 
 
 def compute_thresholds(baseline_dataset, percentiles, no_season: bool = False, rolling_window_size: int = 7,
-                       fixed_value: float = None):
-    """One threshold variable per data variable of the Dataset, merged (threshold.py:207-229)."""
+                       fixed_value: float = None, shard=None):
+    """One threshold variable per data variable of the Dataset, merged (threshold.py:207-229).
+    ``shard``: see compute_threshold."""
     xr = backend()
-    parts = [compute_threshold(baseline_dataset[name], percentiles, no_season, rolling_window_size, fixed_value)
+    parts = [compute_threshold(baseline_dataset[name], percentiles, no_season, rolling_window_size, fixed_value, shard)
              for name in baseline_dataset]
     return xr.merge(parts)
 

@@ -124,7 +124,9 @@ int hdp_percentiles_table_f32(const float *x, int64_t n_cells, int64_t T,
  *   doy_map [T]     int64  threshold row of each time step (metric.py:265-277)
  *   defs    [D][3]  int64  (min_duration, max_break, max_subs)  (metric.py:376-379)
  *   north, south [Y][2] int64 season [start,end) time indices per hemisphere
- *                          (metric.py:221-243; must be increasing and disjoint)
+ *                          (metric.py:221-243).  Increasing, disjoint tables (what compute_hemisphere_ranges
+ *                          builds) run the streaming kernels; any other table (overlapping or unordered ranges,
+ *                          which compute_heatwave_metrics accepts) runs a slower per-series path.
  */
 typedef struct hdp_metrics_plan hdp_metrics_plan;
 
@@ -157,6 +159,21 @@ int hdp_metrics_f32_dev(const hdp_metrics_plan *plan, const float *x_dev,
                         const double *thr_dev, int64_t n_thr_cells,
                         const uint8_t *is_south_dev, int64_t n_cells,
                         int16_t *out_dev, void *stream);
+
+/* Human-readable name of the kernels a launch of this plan runs (thread-local storage). */
+const char *hdp_metrics_plan_describe(const hdp_metrics_plan *plan);
+
+/* ---- time-major device inputs --------------------------------------------------------------------
+ * CMIP data come as (time, lat, lon) (the reference's own workflow chunks them time = -1, lat, lon:
+ * docs/example_cmip_workflow/run_cmip_workflow.py:31-32).  x_tm_dev is [T][pitch_cells] float32, element (t, c) at
+ * x_tm_dev[t * pitch_cells + c]; outputs as for the series-major entry points.  Chunks of cells are transposed into
+ * plan-owned series-major staging buffers (at most 2 x 5 GiB, allocated on first use) on a copy stream of the plan
+ * while the kernels work on the previous chunk; fork/join with `stream` is by events. */
+int hdp_thresholds_f32_tm_dev(const hdp_threshold_plan *plan, const float *x_tm_dev, int64_t pitch_cells,
+                              int64_t n_cells, double *out_dev, void *stream);
+int hdp_metrics_f32_tm_dev(const hdp_metrics_plan *plan, const float *x_tm_dev, int64_t pitch_cells,
+                           const double *thr_dev, int64_t n_thr_cells, const uint8_t *is_south_dev,
+                           int64_t n_cells, int16_t *out_dev, void *stream);
 
 /* Host buffers; out [P][D][n_cells][4][Y] int16 (the reference's block layout,
  * metric.py:368-369, narrowed; the Python adapter widens to int64). */
@@ -213,6 +230,24 @@ int hdp_heat_index_celsius_f32_dev(const float *temp_c_dev, const float *rel_hum
 int hdp_weighted_mean_i16_dev(const int16_t *v_dev, int64_t n_rows, int64_t n, const double *w_dev,
                               double *out_dev, void *stream);
 int hdp_weighted_mean_f64(const double *v, int64_t n_rows, int64_t n, const double *w, double *out);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------------
+ * Grid cells are independent in both passes (reference docs/testing.rst:21; the reference's only parallelism is the
+ * dask split over cells, threshold.py:161-169, metric.py:444-452), so ranks own contiguous cell ranges and compute
+ * without any exchange; the one collective is the all-gather that reassembles the int16 metrics (and, if wanted,
+ * the float64 thresholds) on every rank.  RCCL is linked directly: a caller needs no torch.
+ *   rank 0: hdp_comm_unique_id(id) -> ship the HDP_COMM_ID_BYTES bytes to the other ranks by any channel
+ *   every rank (after hdp_init): hdp_comm_init_rank(id, rank, world)   (collective)
+ *   hdp_allgather_dev(send, bytes, recv, stream): recv [world][bytes] <- every rank's send [bytes]; stream-ordered.
+ *   hdp_allgather_direct_dev: the same result by one grouped ncclSend/ncclRecv per peer (full-mesh xGMI). */
+#define HDP_COMM_ID_BYTES 128
+int hdp_comm_unique_id(void *id_out);
+int hdp_comm_init_rank(const void *id, int rank, int world);
+int hdp_comm_destroy(void);
+int hdp_comm_rank(void);   /* -1 without a communicator */
+int hdp_comm_world(void);  /* 0 without a communicator */
+int hdp_allgather_dev(const void *send_dev, size_t bytes_per_rank, void *recv_dev, void *stream);
+int hdp_allgather_direct_dev(const void *send_dev, size_t bytes_per_rank, void *recv_dev, void *stream);
 
 /* ---- synthetic inputs for bench.py (utils.py:61-78 formula) ---- */
 /* x_dev [n_cells][T]: 20 + 2 sin(2 pi (beta + t)/365) - 10|lat|/90 + noise + trend,

@@ -32,6 +32,13 @@ def max_threads():
     return int(load().oracle_max_threads())
 
 
+def set_threads(n):
+    """OpenMP threads of the following calls; returns the count in effect."""
+    lib = load()
+    lib.oracle_set_threads.restype = C.c_int
+    return int(lib.oracle_set_threads(C.c_int(int(n))))
+
+
 def thresholds(x, win, q):
     lib = load()
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -29,6 +29,11 @@
 #include <omp.h>
 #endif
 
+int oracle_set_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

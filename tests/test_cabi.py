@@ -43,3 +43,18 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src, f"{f} mentions the oracle: the product path must not depend on it"
+
+
+def test_devbuf_is_empty_after_a_failed_allocation(tmp_path):
+    """ADVICE r1: DevBuf::alloc must not record a size for a failed hipMalloc (the scratch guards are `bytes >= need`)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "devbuf_invariant"
+    subprocess.run([hipcc, "-std=c++17", "-O1", "-I", os.path.join(ROOT, "hdp_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "devbuf_invariant.cpp"), "-o", str(exe)], check=True,
+                   capture_output=True, timeout=300)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -66,3 +66,86 @@ def test_two_rank_sharded_metrics_match_unsharded():
         p.join(60)
         assert p.exitcode == 0
     assert ok_thr and ok_met
+
+
+def _adapter_worker(rank, world, port, q):
+    """The product adapters with shard=(rank, world): every rank computes its cells (oracle in place of the GPU calls,
+    as in tests/test_adapter_cpu.py) and must end up with the complete, unsharded Datasets."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import hdp_amd.metric
+    import hdp_amd.threshold
+    from hdp_amd import calendar as cal
+    from hdp_amd import core, utils
+    from oracle import hdp_oracle as orc
+    from tests.helpers import measure_dataset
+
+    calls = []
+
+    def fake_percentiles(x, time_index, cols, qq):
+        calls.append(x.shape[0])
+        return orc.compute_thresholds_cells(np.ascontiguousarray(x), cal.expand_window_table(time_index, cols), qq)
+
+    def fake_planes(x, thr, doy_map, defs, north, south, is_south):
+        x = np.ascontiguousarray(x)
+        full = thr[np.arange(x.shape[0]) % thr.shape[0]]
+        m = orc.compute_metrics_cells(x, full, doy_map, defs, north, south, is_south)
+        return np.ascontiguousarray(np.moveaxis(m.astype(np.int64), 3, 0))
+
+    core.compute_percentiles = fake_percentiles
+    core.compute_heatwave_metric_planes = fake_planes
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        base, lon, lat, bdates = utils.generate_control_array(start_date="1700-01-01", end_date="1703-12-31", add_noise=True)
+        warm, _, _, mdates = utils.generate_warming_array(start_date="2000-01-01", end_date="2003-12-31", add_noise=True)
+        qv = [0.9, 0.95]
+        defs = [[3, 0, 0], [2, 1, 1]]
+        thr_s = hdp_amd.threshold.compute_thresholds(measure_dataset(base, lon, lat, bdates), qv, shard=(rank, world))
+        n_local = list(calls)
+        met_s = hdp_amd.metric.compute_group_metrics(measure_dataset(warm, lon, lat, mdates), thr_s, defs, shard="auto")
+        thr_1 = hdp_amd.threshold.compute_thresholds(measure_dataset(base, lon, lat, bdates), qv)
+        met_1 = hdp_amd.metric.compute_group_metrics(measure_dataset(warm, lon, lat, mdates), thr_1, defs)
+        same_thr = bool(np.array_equal(thr_s["temp_threshold"].values, thr_1["temp_threshold"].values))
+        same_met = all(np.array_equal(met_s[v].values, met_1[v].values) and met_s[v].dims == met_1[v].dims
+                       for v in met_1.data_vars)
+        q.put((rank, n_local, same_thr, bool(same_met)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_adapters_return_the_complete_datasets_on_every_rank():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_adapter_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # 6 grid cells (lon 2 x lat 3): 3 per rank
+    assert got[0][1] == [3] and got[1][1] == [3]
+    assert all(g[2] and g[3] for g in got)
+
+
+def test_comm_entry_points_fail_loudly_without_a_device():
+    """The RCCL communicator lives behind the C ABI (hdp_comm_*, hdp_allgather_dev): exported, bound, and -- like every
+    compute entry point -- HDP_ENODEV without a usable HIP device."""
+    from hdp_amd import _lib
+    lib = _lib.load()
+    assert lib.hdp_comm_world() == 0 and lib.hdp_comm_rank() == -1
+    if lib.hdp_device_count() > 0:
+        pytest.skip("a HIP device is visible; the no-device behaviour cannot be observed here")
+    import ctypes as C
+    buf = C.create_string_buffer(hd.COMM_ID_BYTES)
+    assert lib.hdp_comm_unique_id(buf) == -2
+    assert lib.hdp_comm_init_rank(buf, 0, 1) == -2
+    assert lib.hdp_allgather_dev(None, 8, None, None) == -2
+    assert lib.hdp_allgather_direct_dev(None, 8, None, None) == -2
+    assert hd.current() == (0, 1)

@@ -478,6 +478,9 @@ def test_c3_shape_slice_cross_kernel_properties(monkeypatch):
     assert ti.shape == (365, 100)
     thr = core.compute_percentiles(base, ti, cols, q)
     assert thr.shape == (n, 365, 10) and not np.isnan(thr).any() and np.all(np.diff(thr, axis=2) >= 0)
+    monkeypatch.setenv("HDP_THR_LANE", "0")        # the pipelined kernel instead of the lane-per-column one
+    assert same_f64(thr, core.compute_percentiles(base, ti, cols, q))
+    monkeypatch.delenv("HDP_THR_LANE")
     monkeypatch.setenv("HDP_THR_PIPE", "0")
     assert same_f64(thr, core.compute_percentiles(base, ti, cols, q))
     monkeypatch.setenv("HDP_THR_SELECT", "1")

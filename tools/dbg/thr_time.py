@@ -4,6 +4,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from hdp_amd import _lib, calendar as cal, core, utils
+if os.environ.get('HDP_DBG_LIB'):
+    _lib.LIB_PATH = os.environ['HDP_DBG_LIB']
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 years = int(sys.argv[2]) if len(sys.argv) > 2 else 100
