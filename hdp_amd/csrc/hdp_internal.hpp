@@ -130,6 +130,9 @@ struct hdp_threshold_plan {
   bool lane = false;
   int32_t lane_n = 0;            // register slots per column: the kernel's template parameter N >= S
   size_t lane_lds_bytes = 0;     // dynamic LDS of the lane kernel (its head strips are smaller)
+  int32_t lane_tier_k = 0;       // samples of a column kept in LDS (== S: all of them); the rest in lane_tail
+  int32_t lane_img_pitch = 0;    // LDS words per image column (odd)
+  mutable hdp::DevBuf lane_tail; // tiered image: per-workgroup global tail of the sorted columns
   hdp::DevBuf tixl;              // int32 per block [S][64 * tasks]: byte offset of sample s of local column c
   hdp::DevBuf blk_tixl_off;      // int32 [n_blocks] first element of each block in tixl
   // HDP_THR_* selectors (testing and A/B only; every value gives the same results): read ONCE, when the plan is

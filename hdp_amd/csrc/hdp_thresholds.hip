@@ -40,6 +40,10 @@ struct ThrDev {
   const int32_t *blk_sort_off, *sort_slots;  // one-workgroup-per-cell kernel: LDS column slots a block (re)loads and sorts
   const int32_t *tix, *blk_col_off;  // pipelined kernel: (block column, sample) -> time index
   const int32_t *tixl, *blk_tixl_off;  // lane-per-column kernel: per block [S][64 * tasks] byte offsets of the samples
+  // lane-per-column kernel, tiered image: the top `tier_k` samples of a column live in LDS (column pitch `img_pitch`
+  // words), samples tier_k.. in a per-workgroup global tail [parity][sample - tier_k][tail_pitch] (tier_k == S: all in LDS)
+  int tier_k, img_pitch, tail_pitch;
+  float *tail;
   const float *ninf;                 // four -inf words (what a slot without a sample loads)
   const int32_t *blk_grp_off, *grp_col;  // 16-byte gathers: first column of every group of four, per block
   int SL, n_merge;                             // pitch of tix (8 * lanes per column); merging waves
@@ -755,15 +759,19 @@ __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf
 //  * a group's strip keeps only its 2nd..4th head (the top is the cached top being popped): 24 bytes per (group,
 //    row) in two arrays with compile-time pitch (128 rows), read and written as b128 + b64;
 //  * software-pipelined like merge_row_pl: the next step's reads are issued as soon as the next winner is known.
-constexpr int kLeanRows = 128;                       // strip pitch (rows per block <= 128)
+constexpr int kLeanRows = 128;                       // strip pitch of the blocked form (rows per block <= 128)
+constexpr int kWholeRows = 384;                      // strip pitch of the whole-cell form (all day-of-year rows in one workgroup)
+constexpr int kWholeThreads = 768;                   // 6 merging + 6 producing waves
+constexpr int kTierK = 60;                           // tiered image: samples of a column kept in LDS (plans with S > 64)
 constexpr uint32_t kRawMax = 0x7fe00000u;            // above +inf (0x7f800000), finite as the high word of a double
 constexpr uint32_t kRawMin = 0xffe00000u;            // below -inf (0xff800000)
-template <int NG>
-constexpr size_t lean_strip_bytes() { return size_t(NG) * kLeanRows * 24; }
+template <int NG, int ROWS>
+constexpr size_t lean_strip_bytes() { return size_t(NG) * ROWS * 24; }
 
-template <bool TOP, int NG>
+template <bool TOP, int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
-                                               const uint16_t *cl, int r, const RowFlags &rf, double *orow) {
+                                               const float *tail_cur, const uint16_t *cl, int r, const RowFlags &rf,
+                                               double *orow) {
   static_assert(NG >= 1 && NG <= 4, "group id is two payload bits");
   const int steps = TOP ? pd.steps_top : pd.steps_bot;
   const int nt = TOP ? pd.nt_top : pd.nt_bot;
@@ -774,23 +782,25 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
   auto head = [](uint32_t bits, uint32_t pay) { return __hiloint2double(int(bits), int(pay)); };
   // strips: A[g][row] = (2nd, 3rd) 16 bytes, B[g][row] = 4th 8 bytes
   unsigned char *const sA = strips + size_t(r) * 16;
-  unsigned char *const sB = strips + size_t(NG) * kLeanRows * 16 + size_t(r) * 8;
+  unsigned char *const sB = strips + size_t(NG) * ROWS * 16 + size_t(r) * 8;
   double m[NG];
   {
     // column heads: first (TOP) or last (bottom) sample of each window column; slots past W read a losing sentinel
-    const uint32_t dummy = TOP ? uint32_t(1 + pd.S) * 4u : 0u;  // column 0's trailing / leading sentinel
+      // (tiered image: the marker sits in slot tier_k + 1 -- as the high word of a double it is a NaN, never a head --
+    // and the losing sentinel behind it in slot tier_k + 2; bottom walks never run tiered)
+    const uint32_t dummy = TOP ? uint32_t(1 + (TIER ? pd.tier_k + 1 : pd.S)) * 4u : 0u;  // column 0's trailing / leading sentinel
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       double hd[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = 4 * g + i;
-        const uint32_t pos = (j < pd.W) ? uint32_t(int(cl[j]) * pd.S_pad + (TOP ? 1 : pd.S)) * 4u : dummy;
+        const uint32_t pos = (j < pd.W) ? uint32_t(int(cl[j]) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u : dummy;
         hd[i] = head(*reinterpret_cast<const uint32_t *>(image + pos), pos | uint32_t(g));
       }
       sort_best_first<TOP, 4>(hd);
-      *reinterpret_cast<double2 *>(sA + g * (kLeanRows * 16)) = make_double2(hd[1], hd[2]);
-      *reinterpret_cast<double *>(sB + g * (kLeanRows * 8)) = hd[3];
+      *reinterpret_cast<double2 *>(sA + g * (ROWS * 16)) = make_double2(hd[1], hd[2]);
+      *reinterpret_cast<double *>(sB + g * (ROWS * 8)) = hd[3];
       m[g] = hd[0];
     }
     sort_best_first<TOP, NG>(m);
@@ -807,9 +817,9 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
   auto issue = [&](double top) {
     lo_cur = uint32_t(__double2loint(top));
     g_cur = lo_cur & 3u;
-    nk = *reinterpret_cast<const uint32_t *>(image + (lo_cur & ~3u) + (TOP ? 4 : -4));
-    h12 = *reinterpret_cast<const double2 *>(sA + g_cur * (kLeanRows * 16));
-    h3 = *reinterpret_cast<const double *>(sB + g_cur * (kLeanRows * 8));
+    nk = *reinterpret_cast<const uint32_t *>(image + (lo_cur & 0x3fffcu) + (TOP ? 4 : -4));
+    h12 = *reinterpret_cast<const double2 *>(sA + g_cur * (ROWS * 16));
+    h3 = *reinterpret_cast<const double *>(sB + g_cur * (ROWS * 8));
   };
   double b1 = 0.0, b2 = 0.0, b3 = 0.0;  // previous step's group after insertion (what its write-back stores)
   uint32_t g_prev = 4;
@@ -818,7 +828,31 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
     prev = m[0];
     const uint32_t g = g_cur;
     const bool same = g == g_prev;
-    const double fresh = head(nk, lo_cur + (TOP ? 4u : uint32_t(-4)));
+    uint32_t pay = lo_cur + (TOP ? 4u : uint32_t(-4));
+    if constexpr (TOP && TIER) {
+      // Tiered image: slot tier_k + 1 of a column holds the marker 0x7ff00000 | column (a NaN pattern no sample has;
+      // as a signed int it is above every sample and both sentinels).  Reading it means the column's next sample
+      // lives in the workgroup's global tail: fetch it there.  A head that came from the tail keeps pointing at
+      // slot tier_k (so its "next key" read finds the marker, and with it the column, again) and carries its own
+      // position in payload bits 18..28 under flag bit 30.  Rare by construction (a column must supply more than
+      // tier_k of a window's top ranks), so the wave takes this branch only when some lane needs it.
+      const bool mk = int(nk) >= int(0x7ff00000u);
+      if (__ballot(mk) != 0) {
+        const uint32_t c = nk & 0xfffffu;
+        const uint32_t p1n = (lo_cur & 0x40000000u) ? ((lo_cur >> 18) & 0x7ffu) + 1u : uint32_t(pd.tier_k) + 1u;
+        uint32_t v = kRawMin;  // past the column's last sample: the losing sentinel
+        if (mk && p1n <= uint32_t(pd.S)) {
+          const uint32_t off = ((p1n - uint32_t(pd.tier_k) - 1u) * uint32_t(pd.tail_pitch) + c) * 4u;
+          // sc0 sc1: from L2 -- this CU's L1 may still hold the previous item's bytes of the same address
+          asm volatile("global_load_dword %0, %1, %2 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(off), "s"(tail_cur) : "memory");
+        }
+        if (mk) {
+          nk = v;
+          pay = 0x40000000u | (p1n << 18) | (lo_cur & 0x3ffffu);
+        }
+      }
+    }
+    const double fresh = head(nk, pay);
     const double h1 = same ? b1 : h12.x;
     const double t0 = better(fresh, h1);  // the group's new top
     double m0n = t0;
@@ -832,8 +866,8 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
     const double w2 = worse(w1, h2);
     b2 = better(w2, h3v);
     b3 = worse(w2, h3v);
-    *reinterpret_cast<double2 *>(sA + g * (kLeanRows * 16)) = make_double2(b1, b2);
-    *reinterpret_cast<double *>(sB + g * (kLeanRows * 8)) = b3;
+    *reinterpret_cast<double2 *>(sA + g * (ROWS * 16)) = make_double2(b1, b2);
+    *reinterpret_cast<double *>(sB + g * (ROWS * 8)) = b3;
     g_prev = g;
     m[0] = m0n;
     if constexpr (NG >= 2) {
@@ -857,9 +891,10 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
   }
 }
 
-template <int NG>
+template <int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
-                                                const uint32_t *flags, const uint16_t *cl, int r, double *orow) {
+                                                const float *tail_cur, const uint32_t *flags, const uint16_t *cl, int r,
+                                                double *orow) {
   RowFlags rf{0, 0};
   uint32_t nan_or = 0;
 #pragma unroll
@@ -870,8 +905,8 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
     rf.n_neg += f & 0x7fff;
   }
   if (nan_or >> 31) rf.n_pos = -1;
-  merge_row_lean<true, NG>(pd, image, strips, cl, r, rf, orow);
-  merge_row_lean<false, NG>(pd, image, strips, cl, r, rf, orow);
+  merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow);
+  merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow);
 }
 
 // ---- rank selection (many samples per column) ---------------------------------------------------
@@ -1495,8 +1530,11 @@ constexpr int lane_first_pad_slot(int N) {
 template <int N>
 constexpr int lane_tasks_per_wave() { return N >= 64 ? 1 : (N >= 32 ? 2 : 4); }
 
-template <int N, int NG>
-__global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev pd, const float *__restrict__ x,
+// ROWS = strip pitch: kLeanRows (blocks of <= 128 rows, up to 8 waves, two or three workgroups per CU) or kWholeRows (every
+// day-of-year row of a cell in one 12-wave workgroup per CU: no halo columns -- each column is sorted once per cell --
+// and all 365 merge chains of the cell in flight at once)
+template <int N, int NG, bool TIER, int ROWS>
+__global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, ROWS == kWholeRows ? 3 : 4) void thresholds_lane_kernel(ThrDev pd, const float *__restrict__ x,
                                                                       int64_t n_cells, double *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -1507,12 +1545,12 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev 
 
   size_t off = 0;
   float *colbuf = reinterpret_cast<float *>(smem + off);
-  off += (size_t(pd.ncols_max) * pd.S_pad * 4 + 15) & ~size_t(15);
+  off += (size_t(pd.ncols_max) * pd.img_pitch * 4 + 15) & ~size_t(15);
   uint32_t *flags0 = reinterpret_cast<uint32_t *>(smem + off);  // census words, double-buffered by block parity
   const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
   off += 2 * size_t(flags_pitch) * 4;
   unsigned char *strips = smem + off;  // merge heads: 2nd..4th of every (group, row), see merge_row_lean
-  off += lean_strip_bytes<NG>();
+  off += lean_strip_bytes<NG, ROWS>();
   uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][W] local columns of this block's windows
 
   const int nb = pd.n_blocks;
@@ -1526,12 +1564,15 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev 
   const int n_tasks = (ncols + 63) >> 6;
   const uint32_t pitch4 = uint32_t(n_tasks) * 256u;    // bytes per row of the offset table
   const int32_t *tl = pd.tixl + pd.blk_tixl_off[blk];  // [N][64 * tasks] byte offsets of (sample, local column)
+  // this workgroup's global tail (tiered image), double-buffered by item parity like the census words
+  const size_t tail_half = size_t(max(pd.S - pd.tier_k, 0) + 1) * pd.tail_pitch;
+  float *const tail_wg = pd.tail + size_t(blockIdx.x) * 2 * tail_half;
   for (int i = tid; i < nrows * pd.W; i += int(blockDim.x)) cl_lds[i] = pd.cols_local[size_t(row0) * pd.W + i];
 
   // Roles by SIMD, as in thresholds_pipe_kernel: one merging wave per SIMD first.
   const int n_merge = pd.n_merge;
   const int n_prod = nwaves - n_merge;
-  __shared__ int s_simd[kThrThreads / 64];
+  __shared__ int s_simd[kWholeThreads / 64];
   uint32_t hwid;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
   const int my_simd = int((hwid >> 4) & 3u);
@@ -1643,18 +1684,42 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev 
           const int task = pw + k * n_prod;
           const int lc = task * 64 + lane;
           if (task < n_tasks && lc < ncols) {
-            // lane stride S_pad (odd) words: a store instruction hits 64 different banks
-            float *col = colbuf + lc * pd.S_pad + 1;
+            // lane stride img_pitch (odd) words: a store instruction hits 64 different banks
+            float *col = colbuf + lc * pd.img_pitch + 1;
             // branch-free: slots past the column's last sample all land on its trailing sentinel
+            if constexpr (!TIER) {  // whole column in LDS
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-              // slots below the first possible padding slot always hold a sample: constant LDS offsets (a run-time
-              // min() on every slot gave N loop-invariant addresses, hoisted into N registers)
-              if (i < lane_first_pad_slot(N)) col[i] = __int_as_float(v[k][i]);
-              else col[min(i, S_rt)] = __int_as_float(v[k][i]);
+              for (int i = 0; i < N; ++i) {
+                // slots below the first possible padding slot always hold a sample: constant LDS offsets (a run-time
+                // min() on every slot gave N loop-invariant addresses, hoisted into N registers)
+                if (i < lane_first_pad_slot(N)) col[i] = __int_as_float(v[k][i]);
+                else col[min(i, S_rt)] = __int_as_float(v[k][i]);
+              }
+              col[S_rt] = __uint_as_float(kRawMin);  // loses every descending walk
+            } else {
+              // tiered: the top kTierK samples to LDS, the marker behind them, the rest to the workgroup's global tail
+              // [sample - kTierK][column] (a store instruction writes 64 adjacent columns); slots past S land on a
+              // spare row
+              const float *tbase = tail_wg + size_t(s & 1) * tail_half;  // wave-uniform
+              uint32_t toff = uint32_t(lc) * 4u;                          // one running byte offset (see the loads)
+              const uint32_t trow = uint32_t(pd.tail_pitch) * 4u;
+#pragma unroll
+              for (int i = 0; i < N; ++i) {
+                if (i < kTierK) {
+                  col[i] = __int_as_float(v[k][i]);
+                } else {
+                  // slots past S (padding) all land on the spare row behind the last sample's
+                  const uint32_t o = (i < lane_first_pad_slot(N)) ? toff : uint32_t(lc) * 4u + uint32_t(min(i, S_rt) - kTierK) * trow;
+                  asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(v[k][i]), "s"(tbase) : "memory");
+                  toff += trow;
+                  asm volatile("" : "+v"(toff));
+                }
+              }
+              col[kTierK] = __uint_as_float(0x7ff00000u | uint32_t(lc));
+              col[kTierK + 1] = __uint_as_float(kRawMin);  // what the heads of window slots past W read
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail stores are asm: the barrier's own wait does not count them
             }
             col[-1] = __uint_as_float(kRawMax);    // loses every ascending walk
-            col[S_rt] = __uint_as_float(kRawMin);  // loses every descending walk
           }
         }
       }
@@ -1679,7 +1744,8 @@ __global__ __launch_bounds__(kThrThreads, 4) void thresholds_lane_kernel(ThrDev 
         const uint16_t *cl = cl_lds + mrow * pd.W;
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
 #if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 1))
-        merge_both_lean<NG>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips, flags_m, cl, mrow, orow);
+        merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips,
+                            tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow);
 #endif
       }
       if (clocked) c1 = __builtin_readcyclecounter();
@@ -1836,7 +1902,7 @@ static int launch_thr_pipe(const ThrDev &pd, size_t lds, const float *x, int64_t
 // resident, a multiple of n_blocks (workgroup w works on block w % n_blocks for cells w / n_blocks + k * (grid / n_blocks))
 template <class Kern>
 static int launch_thr_persistent(Kern kern, const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
-                                 int64_t grid_override, int threads, hipStream_t stream) {
+                                 int64_t grid_override, int threads, hipStream_t stream, DevBuf *tail_buf = nullptr) {
   HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   static int n_cu = 0;
@@ -1853,23 +1919,55 @@ static int launch_thr_persistent(Kern kern, const ThrDev &pd, size_t lds, const 
   int64_t resident = int64_t(per_cu) * n_cu;
   if (grid_override > 0) resident = grid_override;
   int64_t grid = std::max<int64_t>(1, std::min<int64_t>(resident / nb, n_cells)) * nb;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, stream, pd, x, n_cells, out);
+  ThrDev pdl = pd;
+  if (tail_buf) {  // tiered image: per-workgroup global tail, two parities of (S - K + 1) rows of tail_pitch floats
+    const size_t need = size_t(grid) * 2 * size_t(std::max(pd.S - pd.tier_k, 0) + 1) * pd.tail_pitch * 4;
+    if (tail_buf->bytes < need) {
+      HDP_HIP_TRY(hipStreamSynchronize(stream));
+      const hipError_t e = tail_buf->alloc(need);
+      if (e != hipSuccess) return set_error(HDP_ENOMEM, "allocating %zu bytes of column-tail scratch failed: %s", need, hipGetErrorString(e));
+    }
+    pdl.tail = tail_buf->as<float>();
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, stream, pdl, x, n_cells, out);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
 }
 
 template <int N>
 static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
-                           int64_t grid_override, hipStream_t stream) {
+                           int64_t grid_override, hipStream_t stream, DevBuf *tail_buf) {
   // merging waves + the producers the widest block needs: at S = 100 that is 2 + 3 waves, and two such workgroups
   // per CU leave every wave the 160 registers a 100-key column takes
   const int tpw = lane_tasks_per_wave<N>();
   const int n_tasks = (pd.ncols_max + 63) / 64;
-  const int threads = std::min<int>(kThrThreads, 64 * (pd.n_merge + (n_tasks + tpw - 1) / tpw));
+  const bool whole = pd.n_blocks == 1 && pd.RP > kLeanRows;  // the plan put every row of a cell into one workgroup
+  const int threads = std::min<int>(whole ? kWholeThreads : kThrThreads, 64 * (pd.n_merge + (n_tasks + tpw - 1) / tpw));
   switch (pd.Wp >> 2) {
-    case 1: return launch_thr_persistent(thresholds_lane_kernel<N, 1>, pd, lds, x, n_cells, out, grid_override, threads, stream);
-    case 2: return launch_thr_persistent(thresholds_lane_kernel<N, 2>, pd, lds, x, n_cells, out, grid_override, threads, stream);
-    case 4: return launch_thr_persistent(thresholds_lane_kernel<N, 4>, pd, lds, x, n_cells, out, grid_override, threads, stream);
+    case 1:
+      if constexpr (N > 64) {
+        if (pd.tier_k < pd.S && whole)
+          return launch_thr_persistent(thresholds_lane_kernel<N, 1, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+        if (pd.tier_k < pd.S)
+          return launch_thr_persistent(thresholds_lane_kernel<N, 1, true, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+      }
+      return launch_thr_persistent(thresholds_lane_kernel<N, 1, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
+    case 2:
+      if constexpr (N > 64) {
+        if (pd.tier_k < pd.S && whole)
+          return launch_thr_persistent(thresholds_lane_kernel<N, 2, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+        if (pd.tier_k < pd.S)
+          return launch_thr_persistent(thresholds_lane_kernel<N, 2, true, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+      }
+      return launch_thr_persistent(thresholds_lane_kernel<N, 2, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
+    case 4:
+      if constexpr (N > 64) {
+        if (pd.tier_k < pd.S && whole)
+          return launch_thr_persistent(thresholds_lane_kernel<N, 4, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+        if (pd.tier_k < pd.S)
+          return launch_thr_persistent(thresholds_lane_kernel<N, 4, true, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+      }
+      return launch_thr_persistent(thresholds_lane_kernel<N, 4, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
     default: return set_error(HDP_EUNSUP, "lane-per-column kernel: unsupported window width");
   }
 }
@@ -1921,9 +2019,11 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
   const ThrVariant v = thr_variant(plan, 0);
   if (v.lane)
     snprintf(buf, sizeof buf,
-             "thresholds_lane_kernel<N=%d,NG=%d> (one lane per column: register merge-exchange sort; %d merging waves; "
-             "%d rows x %d blocks, %zu B LDS)",
-             plan->lane_n, plan->Wp >> 2, plan->n_merge, plan->rows_per_block, plan->n_blocks, plan->lane_lds_bytes);
+             "thresholds_lane_kernel<N=%d,NG=%d%s> (one lane per column: register merge-exchange sort; %d merging waves; "
+             "%d rows x %d blocks, %zu B LDS%s)",
+             plan->lane_n, plan->Wp >> 2, plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : "", plan->n_merge,
+             plan->rows_per_block, plan->n_blocks, plan->lane_lds_bytes,
+             plan->lane_tier_k < plan->S ? "; top 60 samples of a column in LDS, the rest in a global tail" : "");
   else if (v.pipe)
     snprintf(buf, sizeof buf,
              "thresholds_pipe_kernel<LPC=%d,%s,NG=%d> (register sort producers + %d merging waves; %d rows x %d blocks, "
@@ -1982,6 +2082,10 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.n_merge = plan->n_merge;
   pd.tixl = plan->tixl.as<int32_t>();
   pd.blk_tixl_off = plan->blk_tixl_off.as<int32_t>();
+  pd.tier_k = plan->lane_tier_k;
+  pd.img_pitch = plan->lane_img_pitch;
+  pd.tail_pitch = ((plan->ncols_max + 63) / 64) * 64;
+  pd.tail = nullptr;
   pd.grid_override = plan->opt_grid;
 #ifdef HDP_DEBUG_ABLATIONS
   pd.debug = getenv("HDP_THR_DEBUG") ? atoi(getenv("HDP_THR_DEBUG")) : 0;
@@ -2000,14 +2104,14 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.select = var.select;
   if (var.lane) {
     switch (plan->lane_n) {
-      case 8: return launch_thr_lane<8>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 16: return launch_thr_lane<16>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 24: return launch_thr_lane<24>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 32: return launch_thr_lane<32>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 48: return launch_thr_lane<48>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 64: return launch_thr_lane<64>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 80: return launch_thr_lane<80>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
-      case 100: return launch_thr_lane<100>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream);
+      case 8: return launch_thr_lane<8>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
+      case 16: return launch_thr_lane<16>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
+      case 24: return launch_thr_lane<24>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
+      case 32: return launch_thr_lane<32>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
+      case 48: return launch_thr_lane<48>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
+      case 64: return launch_thr_lane<64>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
+      case 80: return launch_thr_lane<80>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
+      case 100: return launch_thr_lane<100>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
       default: return set_error(HDP_EUNSUP, "lane-per-column kernel: no instantiation for %d slots", plan->lane_n);
     }
   }
@@ -2235,7 +2339,31 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     return worst;
   };
   const size_t kMaxLds = 160 * 1024 - 1024;
-  int rows = opt_rows;
+  // Whole-cell form of the lane-per-column kernel: with the tiered image (top kTierK samples of a column in LDS) all
+  // n_doy columns and the heads of all n_doy rows fit one CU's LDS, so one 12-wave workgroup handles a whole cell:
+  // no halo columns (every column is sorted once per cell, not once per block) and 365 instead of 244 merge chains
+  // in flight per CU -- the chains are latency-bound, their number is the kernel's throughput.
+  bool whole = false;
+  size_t whole_lds = 0;
+  {
+    const int ngw0 = pl->Wp >> 2;
+    const bool tier_ok = S > 64 && S <= 100 && pl->steps_bot == 0 && (ngw0 == 1 || ngw0 == 2 || ngw0 == 4) &&
+                         pl->opt_lane != 0 && pl->opt_pipe != 0 && opt_rows <= 0 && hdp::env_option("HDP_THR_WHOLE", 1) != 0;
+    if (tier_ok && n_doy <= hdp::kWholeRows && n_doy > hdp::kLeanRows) {
+      int ip = hdp::kTierK + 3;
+      if ((ip & 1) == 0) ++ip;
+      size_t b = (size_t(n_doy) * ip * 4 + 15) & ~size_t(15);
+      b += 2 * ((size_t(n_doy) * 4 + 15) & ~size_t(15));
+      b += size_t(ngw0) * hdp::kWholeRows * 24;
+      b += (size_t(n_doy) * W * 2 + 15) & ~size_t(15);
+      const int waves = 2 * int((n_doy + 63) / 64);
+      if (b <= kMaxLds && waves * 64 <= hdp::kWholeThreads) {
+        whole = true;
+        whole_lds = b;
+      }
+    }
+  }
+  int rows = whole ? (int)n_doy : opt_rows;
   if (rows <= 0) {
     // largest row count whose worst block fits `cap` bytes of LDS
     auto fit = [&](size_t cap) -> int {
@@ -2255,9 +2383,13 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     }
   }
   const bool rows_forced = opt_rows > 0;
-  rows = (int)std::min<int64_t>(rows, std::min<int64_t>(n_doy, hdp::kThrThreads));
+  rows = (int)std::min<int64_t>(rows, std::min<int64_t>(n_doy, whole ? hdp::kWholeThreads : hdp::kThrThreads));
   int cm = 0;
-  if (rows <= 0 || max_lds_for_rows(rows, &cm) > kMaxLds) {
+  if (whole) {
+    std::vector<int> all;
+    cols_of_block(0, rows, all);
+    cm = (int)all.size();
+  } else if (rows <= 0 || max_lds_for_rows(rows, &cm) > kMaxLds) {
     delete pl;
     return set_error(HDP_EUNSUP, "window of %lld x %lld samples does not fit the 160 KiB LDS",
                      (long long)W, (long long)S);
@@ -2285,8 +2417,8 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     if (np < 1) return false;
     return (ncols_max + 63) / 64 <= np * hdp::lane_tasks_per_wave_rt(lane_n);
   };
-  bool lane = lane_ok(rows, cm);
-  bool pipe = pipe_ok(rows, cm);
+  bool lane = whole || lane_ok(rows, cm);
+  bool pipe = !whole && pipe_ok(rows, cm);
   if (lane_n && !lane && !rows_forced) {
     for (int r = rows - 1; r >= std::max(1, rows / 2); --r) {
       const int nb = int((n_doy + r - 1) / r);
@@ -2302,14 +2434,24 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   pl->lane = lane;
   pl->lane_n = lane_n;
   if (lane) {
+    // Tiered image: the merge is a chain of dependent steps per row, so the kernel's throughput is the number of rows
+    // resident per CU over the step latency, and the rows are bounded by LDS.  With more than 64 samples per column
+    // and top-side quantiles only, a column keeps its top kTierK samples in LDS (a window's deepest rank rarely
+    // draws more than that from one column) and the rest in a global tail: three workgroups per CU instead of two.
+    // (only the whole-cell form gains from it: three 5-wave workgroups of the blocked form do not fit a CU's
+    // register file side by side, measured)
+    pl->lane_tier_k = whole ? hdp::kTierK : (int32_t)S;
+    int ip = pl->lane_tier_k < S ? pl->lane_tier_k + 3 : spad;  // sentinel, samples, marker, sentinel
+    if ((ip & 1) == 0) ++ip;
+    pl->lane_img_pitch = ip;
     // the lane kernel's own LDS layout: image, census (x2), lean head strips (24 bytes per group and row, pitch
     // kLeanRows), window column lists
-    size_t b = (size_t(cm) * spad * 4 + 15) & ~size_t(15);
+    size_t b = (size_t(cm) * ip * 4 + 15) & ~size_t(15);
     b += 2 * ((size_t(cm) * 4 + 15) & ~size_t(15));
     b += size_t(ngw) * hdp::kLeanRows * 24;
     b += (size_t(rows) * W * 2 + 15) & ~size_t(15);
-    pl->lane_lds_bytes = b;
-    if (b > kMaxLds || rows > hdp::kLeanRows) pl->lane = false;
+    pl->lane_lds_bytes = whole ? whole_lds : b;
+    if (!whole && (b > kMaxLds || rows > hdp::kLeanRows)) pl->lane = false;
   }
   if (lpc && !pipe && !lane && !rows_forced) {
     for (int r = rows - 1; r >= std::max(1, rows / 2); --r) {

@@ -71,7 +71,7 @@ def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
         want = c_oracle.thresholds(x, win, q)
 
     def run(**env):
-        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE"):
+        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE", "HDP_THR_WHOLE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -79,10 +79,32 @@ def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
 
     got = run()                                        # lane-per-column kernel where the plan allows it
     assert same_f64(got, want)
+    assert same_f64(run(HDP_THR_WHOLE="0"), want)     # its blocked form where the default is the whole-cell one
     assert same_f64(run(HDP_THR_LANE="0"), want)      # pipelined kernel (16-byte gathers on regular calendars)
     assert same_f64(run(HDP_THR_LANE="0", HDP_THR_VEC="0"), want)   # pipelined kernel, one dword per (column, sample)
     assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="0"), want)   # one workgroup per cell, merge
     assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="1"), want)   # same, rank selection per (row, rank)
+
+
+def test_tiered_image_deep_columns_reach_the_global_tail():
+    """Whole-cell lane kernel: a column keeps its top 60 samples in LDS and the rest in a global tail.  With a steep
+    seasonal slope and little noise the warmest column of a window supplies (almost) all of its 100 samples to the
+    top 10 %, so the merges walk deep into the tails -- and must still match the oracle bit for bit."""
+    rng = np.random.default_rng(11)
+    dates = orc.noleap_date_range("0001-01-01", "0100-12-31")
+    T = dates.size
+    t = np.arange(T)
+    n_cells = 4
+    x = (20 * np.sin(2 * np.pi * t / 365.0)[None, :] + rng.normal(0, 0.01, size=(n_cells, T))).astype(np.float32)
+    x[1] = np.round(x[1], 1)          # ties
+    x[2, ::7] = -np.inf               # special values in the tails
+    x[3] += (t / 3650.0).astype(np.float32)   # trend: recent years on top of every column
+    ti, cols = cal.window_columns(dates, 7)
+    q = list(np.arange(0.9, 1.0, 0.01))
+    win = cal.expand_window_table(ti, cols)
+    with np.errstate(invalid="ignore"):
+        want = c_oracle.thresholds(x, win, q)
+    assert same_f64(core.compute_percentiles(x, ti, cols, q), want)
 
 
 def test_pipelined_kernel_many_cells_vs_single_cell_launches():
@@ -134,9 +156,9 @@ def test_random_calendars_windows_and_quantiles(seed, monkeypatch):
     win = cal.expand_window_table(ti, cols)
     with np.errstate(invalid="ignore"):
         want = c_oracle.thresholds(x, win, q)
-    for env in ({}, {"HDP_THR_LANE": "0"}, {"HDP_THR_LANE": "0", "HDP_THR_VEC": "0"},
+    for env in ({}, {"HDP_THR_WHOLE": "0"}, {"HDP_THR_LANE": "0"}, {"HDP_THR_LANE": "0", "HDP_THR_VEC": "0"},
                 {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "0"}, {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "1"}):
-        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE"):
+        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE", "HDP_THR_WHOLE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -35,3 +35,4 @@ run("S100-vec-ng4-both", "0001-01-01", "0100-12-31", 7, [0.0, 0.03, 0.5, 0.97, 1
 run("nospecial", "0001-01-01", "0100-12-31", 7, [0.0, 0.03, 0.5, 0.97, 1.0], 3, False)
 run("S70", "0001-01-01", "0070-03-17", 7, [0.1, 0.9, 0.99], 4, True)
 run("S5", "0001-01-01", "0005-12-31", 7, [0.0, 0.9, 1.0], 11, True)
+run("S100-vec-ng4-top", "0001-01-01", "0100-12-31", 7, list(np.arange(0.9, 1.0, 0.01)), 5, False)
