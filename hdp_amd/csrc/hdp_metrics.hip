@@ -1367,26 +1367,29 @@ int launch_weighted_row_mean_f64(const double *v_dev, int64_t n_rows, int64_t n,
 // cell axis, writes along time.  HBM-bound: 8 bytes of traffic per element.
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, int64_t src_pitch,
                                                         int64_t T, int64_t n, float *__restrict__ dst) {
-  __shared__ float tile[64][65];
-  const int64_t t0 = int64_t(blockIdx.y) * 64, c0 = int64_t(blockIdx.x) * 64;
+  // 32 time steps x 64 cells per workgroup: 8.3 KB of LDS, so the copy fits beside the whole-cell thresholds
+  // kernel (143 KB of a CU's 160 KB) and runs WHILE it computes; rows of 256 B in, 128 B out
+  __shared__ float tile[32][65];
+  const int64_t t0 = int64_t(blockIdx.y) * 32, c0 = int64_t(blockIdx.x) * 64;
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;  // 64 x 4 threads
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const int64_t t = t0 + ly + 4 * i, c = c0 + lx;
     if (t < T && c < n) tile[ly + 4 * i][lx] = src[t * src_pitch + c];
   }
   __syncthreads();
+  const int tx = threadIdx.x & 31, cy = threadIdx.x >> 5;  // 32 time steps x 8 cells per pass
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int64_t c = c0 + ly + 4 * i, t = t0 + lx;
-    if (t < T && c < n) dst[c * T + t] = tile[lx][ly + 4 * i];
+  for (int i = 0; i < 8; ++i) {
+    const int64_t c = c0 + cy + 8 * i, t = t0 + tx;
+    if (t < T && c < n) dst[c * T + t] = tile[tx][cy + 8 * i];
   }
 }
 
 int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
                      hipStream_t stream) {
   if (T * n == 0) return HDP_OK;
-  dim3 grid((unsigned)((n + 63) / 64), (unsigned)((T + 63) / 64));
+  dim3 grid((unsigned)((n + 63) / 64), (unsigned)((T + 31) / 32));
   HDP_REQUIRE(grid.y < 65536, HDP_EUNSUP, "time axis too long for the transpose launch");
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
   HDP_HIP_TRY(hipGetLastError());
