@@ -768,10 +768,64 @@ constexpr uint32_t kRawMin = 0xffe00000u;            // below -inf (0xff800000)
 template <int NG, int ROWS>
 constexpr size_t lean_strip_bytes() { return size_t(NG) * ROWS * 24; }
 
+// The emission tables of one merge direction held ACROSS THE LANES of a few registers: lane k has target k's rank, its
+// (quantile | kind << 16) word and that quantile's parameters.  An emission then reads them with v_readlane (a
+// wave-uniform k) instead of a chain of scalar loads whose latency the merging wave sat out ten times per row (0.8 of
+// 7.9 ms per 65 536 cells at C3, measured by ablation).  Loaded once per kernel; plans with more than 64 targets per
+// direction keep the scalar-load form.
+struct TgtLanes {
+  int rank, slot, mode;
+  double w_lo, w_hi;
+  bool ok;
+};
+template <bool TOP>
+__device__ __forceinline__ TgtLanes load_tgt_lanes(const ThrDev &pd, int lane) {
+  const int nt = TOP ? pd.nt_top : pd.nt_bot;
+  const int2 *tgt = TOP ? pd.tgt_top : pd.tgt_bot;
+  TgtLanes t{-1, 0, 0, 0.0, 0.0, nt <= 64};
+  if (t.ok && lane < nt) {
+    const int2 r = tgt[lane];
+    const QuantileParam qp = pd.qp[r.y & 0xffff];
+    t.rank = r.x;
+    t.slot = r.y;
+    t.mode = qp.mode;
+    t.w_lo = qp.w_lo;
+    t.w_hi = qp.w_hi;
+  }
+  return t;
+}
+__device__ __forceinline__ double readlane_f64(double v, int k) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+}
+template <bool TOP>
+__device__ __forceinline__ void emit_targets_lanes(const ThrDev &pd, const TgtLanes &tl, int nt, int &k, int &next_rank,
+                                                   int step, int best, int prev, const RowFlags &rf, double *orow) {
+  int kk = __builtin_amdgcn_readfirstlane(k);
+  int rank_k = step;
+  do {
+    const int slot = __builtin_amdgcn_readlane(tl.slot, kk);
+    const int p = slot & 0xffff, kind = slot >> 16;
+    const float fb = __int_as_float(best), fp = __int_as_float(prev);
+    float lo = fb, hi = fb;
+    if (kind == E_TOP_PAIR) hi = fp;
+    if (kind == E_BOT_PAIR) lo = fp;
+    QuantileParam qp;
+    qp.mode = __builtin_amdgcn_readlane(tl.mode, kk);
+    qp.pad = 0;
+    qp.w_lo = readlane_f64(tl.w_lo, kk);
+    qp.w_hi = readlane_f64(tl.w_hi, kk);
+    orow[size_t(p) * pd.n_doy] = finish_quantile(qp, lo, hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
+    ++kk;
+    rank_k = kk < nt ? __builtin_amdgcn_readlane(tl.rank, min(kk, 63)) : -1;
+  } while (rank_k == step);
+  k = kk;
+  next_rank = rank_k;
+}
+
 template <bool TOP, int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
                                                const float *tail_cur, const uint16_t *cl, int r, const RowFlags &rf,
-                                               double *orow) {
+                                               double *orow, const TgtLanes &tl) {
   static_assert(NG >= 1 && NG <= 4, "group id is two payload bits");
   const int steps = TOP ? pd.steps_top : pd.steps_bot;
   const int nt = TOP ? pd.nt_top : pd.nt_bot;
@@ -806,7 +860,7 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
     sort_best_first<TOP, NG>(m);
   }
   int k = 0;
-  int next_rank = nt > 0 ? ldk(&tgt[0]).x : -1;
+  int next_rank = nt > 0 ? (tl.ok ? __builtin_amdgcn_readlane(tl.rank, 0) : ldk(&tgt[0]).x) : -1;
   double prev = head(TOP ? kRawMin : kRawMax, 0);
 
   uint32_t nk;      // next key (float bits) of the popped column
@@ -886,7 +940,19 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
     const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
     for (; step < stop; ++step) do_step();
     if (step >= steps) break;
-    emit_targets<TOP, true>(pd, tgt, nt, k, next_rank, step, __double2hiint(m[0]), __double2hiint(prev), rf, true, orow);
+#if defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 4)
+    {  // ablation: no emission (timing only)
+      int kk = k + 1;
+      while (kk < nt && ldk(&tgt[kk]).x == step) ++kk;
+      k = kk;
+      next_rank = kk < nt ? ldk(&tgt[kk]).x : -1;
+    }
+#else
+    if (tl.ok)  // wave-uniform
+      emit_targets_lanes<TOP>(pd, tl, nt, k, next_rank, step, __double2hiint(m[0]), __double2hiint(prev), rf, orow);
+    else
+      emit_targets<TOP, true>(pd, tgt, nt, k, next_rank, step, __double2hiint(m[0]), __double2hiint(prev), rf, true, orow);
+#endif
     next_rank = __builtin_amdgcn_readfirstlane(next_rank);
   }
 }
@@ -894,7 +960,7 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
 template <int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
                                                 const float *tail_cur, const uint32_t *flags, const uint16_t *cl, int r,
-                                                double *orow) {
+                                                double *orow, const TgtLanes &tl_top, const TgtLanes &tl_bot) {
   RowFlags rf{0, 0};
   uint32_t nan_or = 0;
 #pragma unroll
@@ -905,8 +971,8 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
     rf.n_neg += f & 0x7fff;
   }
   if (nan_or >> 31) rf.n_pos = -1;
-  merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow);
-  merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow);
+  merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_top);
+  merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_bot);
 }
 
 // ---- rank selection (many samples per column) ---------------------------------------------------
@@ -1733,6 +1799,7 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, R
       }
     }
   } else {
+    const TgtLanes tl_top = load_tgt_lanes<true>(pd, lane), tl_bot = load_tgt_lanes<false>(pd, lane);
     for (int64_t s = 0; s <= n_items; ++s) {
       const uint32_t *flags_m = flags0 + int((s + 1) & 1) * flags_pitch;  // census of block s - 1
       unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -1745,7 +1812,7 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, R
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
 #if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 1))
         merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips,
-                            tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow);
+                            tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow, tl_top, tl_bot);
 #endif
       }
       if (clocked) c1 = __builtin_readcyclecounter();
