@@ -377,6 +377,70 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
   }
 }
 
+// ---- the same kernel with the percentiles in PAIRS --------------------------------------------------------------
+// exceed_kernel handles four percentiles per pass, so P = 10 costs twelve compare + lane-write slots per word, and it
+// re-derives every threshold address from a packed day-of-year index (three instructions per word and pass): 51 vector
+// instructions per 64-day word.  Here a pass handles two percentiles (no dead slots for any even P; one for odd P), the
+// staged thresholds are [n_doy][2 * ceil(P/2)] so a lane's pair is ONE ds_read_b64 (row pitch 40 bytes at P = 10:
+// consecutive day-of-year rows fall on distinct bank pairs), and the lane's 32 LDS row addresses of a chunk sit in
+// registers and simply advance by 8 bytes per pass: 2 compares + 4 lane writes per word and pass, one add per word and
+// pass, i.e. 35 instead of 51 vector instructions per word at P = 10.  Same words, same scratch layout.
+template <int CW>
+__global__ __launch_bounds__(256) void exceed_pairs_kernel(MetDev md, const float *__restrict__ x,
+                                                           const double *__restrict__ thr, int64_t n_thr_cells,
+                                                           int64_t n_cells) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *thr32 = reinterpret_cast<float *>(smem);  // [n_doy][PP], f32 rounded toward -inf
+  const int NP2 = (md.P + 1) >> 1, PP = 2 * NP2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t cell = blockIdx.x;
+  {
+    const double *tc = thr + (cell % n_thr_cells) * int64_t(md.n_doy) * md.P;
+    for (int doy = threadIdx.x; doy < md.n_doy; doy += 256)
+      for (int q = 0; q < PP; ++q)
+        thr32[doy * PP + q] = f64_to_f32_down(tc[int64_t(min(q, md.P - 1)) * md.n_doy + doy]);
+  }
+  __syncthreads();
+  const float *xc = x + cell * int64_t(md.T);
+  const int n_words = (md.T + 63) >> 6;
+  const int Tp = n_words * 64;
+  unsigned long long *brow = md.bits_g + cell * md.P * int64_t(md.words_pad);
+  const uint32_t row_bytes = uint32_t(PP) * 4u;
+  for (int w0 = wave * CW; w0 < n_words; w0 += 4 * CW) {
+    float xr[CW];
+    uint32_t ad[CW];  // LDS byte address of this lane's threshold row for word w (advances 8 bytes per pass)
+#pragma unroll
+    for (int w = 0; w < CW; ++w) {
+      const int t = (w0 + w) * 64 + lane;
+      xr[w] = (t < md.T) ? xc[t] : -INFINITY;
+      ad[w] = ((t < Tp) ? uint32_t(md.doy_map[t]) : 0u) * row_bytes;
+    }
+    for (int g = 0; g < NP2; ++g) {
+      uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+      float2 tc = *reinterpret_cast<const float2 *>(smem + ad[0]), tn = tc;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) {
+        if (w + 1 < CW) tn = *reinterpret_cast<const float2 *>(smem + ad[w + 1]);
+        const float xv = xr[w];
+        const unsigned long long m0 = __ballot(xv > tc.x);
+        const unsigned long long m1 = __ballot(xv > tc.y);
+        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %4, %8\n\tv_writelane_b32 %1, %5, %8\n\t"
+                     "v_writelane_b32 %2, %6, %8\n\tv_writelane_b32 %3, %7, %8"
+                     : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1)
+                     : "s"((uint32_t)m0), "s"((uint32_t)(m0 >> 32)), "s"((uint32_t)m1), "s"((uint32_t)(m1 >> 32)), "i"(w));
+        ad[w] += 8u;  // next pass: the next pair of this row
+        tc = tn;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < CW) {
+        brow[int64_t(2 * g) * md.words_pad + w0 + lane] = ((unsigned long long)hi0 << 32) | lo0;
+        if (2 * g + 1 < md.P) brow[int64_t(2 * g + 1) * md.words_pad + w0 + lane] = ((unsigned long long)hi1 << 32) | lo1;
+      }
+    }
+  }
+}
+
 template <bool SPLIT>
 __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
     MetDev md, const float *__restrict__ x, const double *__restrict__ thr, int64_t n_thr_cells,
@@ -1666,12 +1730,17 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   HDP_REQUIRE(!split || plan->bits_scratch.p, HDP_ENOMEM, "exceedance scratch is not allocated");
   HDP_REQUIRE(by_cells || plan->rows_scratch.p, HDP_ENOMEM, "metrics row scratch is not allocated");
   md.bits_g = plan->bits_scratch.as<unsigned long long>();
-  const size_t lds_a = (size_t((md.P + kQB - 1) / kQB * kQB) * md.n_doy * 4 + 15) & ~size_t(15);
+  const bool pairs = plan->opt_pairs != 0;  // exceed_pairs_kernel (two percentiles per pass) instead of exceed_kernel (four)
+  const size_t lds_a = pairs ? ((size_t((md.P + 1) / 2 * 2) * md.n_doy * 4 + 15) & ~size_t(15))
+                             : ((size_t((md.P + kQB - 1) / kQB * kQB) * md.n_doy * 4 + 15) & ~size_t(15));
   const bool short_record = ((md.T + 63) >> 6) <= 64;  // at most two 32-word chunks: use 16-word chunks, all four waves
   if (split) {
     HDP_REQUIRE(lds_a <= kLdsPerCU - 1024, HDP_EUNSUP, "too many percentiles for the exceedance kernel");
-    HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(short_record ? exceed_kernel<16> : exceed_kernel<32>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    const void *ek = pairs ? (short_record ? reinterpret_cast<const void *>(exceed_pairs_kernel<16>)
+                                           : reinterpret_cast<const void *>(exceed_pairs_kernel<32>))
+                           : (short_record ? reinterpret_cast<const void *>(exceed_kernel<16>)
+                                           : reinterpret_cast<const void *>(exceed_kernel<32>));
+    HDP_HIP_TRY(hipFuncSetAttribute(ek, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
   }
   auto kern_rows = split ? metrics_kernel_uniform<true> : (uniform ? metrics_kernel_uniform<false> : metrics_kernel_general);
   if (!by_cells)
@@ -1712,7 +1781,11 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
         const int rc = launch_transpose(x_dev + c0, tm_pitch, md.T, nc, const_cast<float *>(x_b), sx);
         if (rc != HDP_OK) return rc;
       }
-      if (short_record)
+      if (pairs && short_record)
+        hipLaunchKernelGGL(exceed_pairs_kernel<16>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
+      else if (pairs)
+        hipLaunchKernelGGL(exceed_pairs_kernel<32>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
+      else if (short_record)
         hipLaunchKernelGGL(exceed_kernel<16>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
       else
         hipLaunchKernelGGL(exceed_kernel<32>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
