@@ -839,19 +839,38 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
   unsigned char *const sB = strips + size_t(NG) * ROWS * 16 + size_t(r) * 8;
   double m[NG];
   {
-    // column heads: first (TOP) or last (bottom) sample of each window column; slots past W read a losing sentinel
-      // (tiered image: the marker sits in slot tier_k + 1 -- as the high word of a double it is a NaN, never a head --
-    // and the losing sentinel behind it in slot tier_k + 2; bottom walks never run tiered)
-    const uint32_t dummy = TOP ? uint32_t(1 + (TIER ? pd.tier_k + 1 : pd.S)) * 4u : 0u;  // column 0's trailing / leading sentinel
+    // column heads: first (TOP) or last (bottom) sample of each window column.  The row's column list is padded to
+    // 4 * NG entries with the pseudo column (all sentinels), so this is branch-free: two 16-byte reads of the list,
+    // every head read in flight at once.
+    uint32_t pos[4 * NG];
+    {
+      const uint4 *cl4 = reinterpret_cast<const uint4 *>(cl);
+#pragma unroll
+      for (int v4 = 0; v4 < NG / 2 + (NG & 1); ++v4) {
+        uint32_t wv[4];
+        if (NG == 1) {
+          const uint2 h = *reinterpret_cast<const uint2 *>(cl);
+          wv[0] = h.x; wv[1] = h.y; wv[2] = wv[3] = 0;
+        } else {
+          const uint4 q4 = cl4[v4];
+          wv[0] = q4.x; wv[1] = q4.y; wv[2] = q4.z; wv[3] = q4.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j0 = v4 * 8 + 2 * u;
+          if (j0 < 4 * NG) pos[j0] = uint32_t(int(wv[u] & 0xffffu) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
+          if (j0 + 1 < 4 * NG) pos[j0 + 1] = uint32_t(int(wv[u] >> 16) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
+        }
+      }
+    }
+    uint32_t kb[4 * NG];
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) kb[j] = *reinterpret_cast<const uint32_t *>(image + pos[j]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       double hd[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 4 * g + i;
-        const uint32_t pos = (j < pd.W) ? uint32_t(int(cl[j]) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u : dummy;
-        hd[i] = head(*reinterpret_cast<const uint32_t *>(image + pos), pos | uint32_t(g));
-      }
+      for (int i = 0; i < 4; ++i) hd[i] = head(kb[4 * g + i], pos[4 * g + i] | uint32_t(g));
       sort_best_first<TOP, 4>(hd);
       *reinterpret_cast<double2 *>(sA + g * (ROWS * 16)) = make_double2(hd[1], hd[2]);
       *reinterpret_cast<double *>(sB + g * (ROWS * 8)) = hd[3];
@@ -1611,13 +1630,13 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, R
 
   size_t off = 0;
   float *colbuf = reinterpret_cast<float *>(smem + off);
-  off += (size_t(pd.ncols_max) * pd.img_pitch * 4 + 15) & ~size_t(15);
+  off += (size_t(pd.ncols_max + 1) * pd.img_pitch * 4 + 15) & ~size_t(15);  // + one pseudo column of sentinels
   uint32_t *flags0 = reinterpret_cast<uint32_t *>(smem + off);  // census words, double-buffered by block parity
   const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
   off += 2 * size_t(flags_pitch) * 4;
   unsigned char *strips = smem + off;  // merge heads: 2nd..4th of every (group, row), see merge_row_lean
   off += lean_strip_bytes<NG, ROWS>();
-  uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][W] local columns of this block's windows
+  uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][4 * NG] local columns of this block's windows (slots past W: the pseudo column)
 
   const int nb = pd.n_blocks;
   const int blk = int(blockIdx.x) % nb;
@@ -1633,7 +1652,14 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, R
   // this workgroup's global tail (tiered image), double-buffered by item parity like the census words
   const size_t tail_half = size_t(max(pd.S - pd.tier_k, 0) + 1) * pd.tail_pitch;
   float *const tail_wg = pd.tail + size_t(blockIdx.x) * 2 * tail_half;
-  for (int i = tid; i < nrows * pd.W; i += int(blockDim.x)) cl_lds[i] = pd.cols_local[size_t(row0) * pd.W + i];
+  for (int i = tid; i < nrows * 4 * NG; i += int(blockDim.x)) {
+    const int r = i / (4 * NG), j = i % (4 * NG);
+    cl_lds[i] = (j < pd.W) ? pd.cols_local[size_t(row0 + r) * pd.W + j] : uint16_t(pd.ncols_max);
+  }
+  // the pseudo column: every slot a head could start from reads as a loser (top walks start at slot 1, bottom walks at
+  // slot S); it is never written again
+  for (int i = tid; i < pd.img_pitch; i += int(blockDim.x))
+    colbuf[size_t(pd.ncols_max) * pd.img_pitch + i] = __uint_as_float(i <= 2 ? kRawMin : kRawMax);
 
   // Roles by SIMD, as in thresholds_pipe_kernel: one merging wave per SIMD first.
   const int n_merge = pd.n_merge;
@@ -1808,7 +1834,7 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, R
       if (s >= 1 && mrow < nrows) {
         const int64_t cell = first_cell + (s - 1) * wg_per_blk;
         const int row = row0 + mrow;
-        const uint16_t *cl = cl_lds + mrow * pd.W;
+        const uint16_t *cl = cl_lds + mrow * (4 * NG);
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
 #if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 1))
         merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips,
@@ -2419,10 +2445,10 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     if (tier_ok && n_doy <= hdp::kWholeRows && n_doy > hdp::kLeanRows) {
       int ip = hdp::kTierK + 3;
       if ((ip & 1) == 0) ++ip;
-      size_t b = (size_t(n_doy) * ip * 4 + 15) & ~size_t(15);
+      size_t b = (size_t(n_doy + 1) * ip * 4 + 15) & ~size_t(15);
       b += 2 * ((size_t(n_doy) * 4 + 15) & ~size_t(15));
       b += size_t(ngw0) * hdp::kWholeRows * 24;
-      b += (size_t(n_doy) * W * 2 + 15) & ~size_t(15);
+      b += (size_t(n_doy) * 4 * ngw0 * 2 + 15) & ~size_t(15);
       const int waves = 2 * int((n_doy + 63) / 64);
       if (b <= kMaxLds && waves * 64 <= hdp::kWholeThreads) {
         whole = true;
@@ -2477,7 +2503,8 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   };
   // lane-per-column kernel: every producer wave sorts (and holds) up to lane_tasks_per_wave tasks of 64 columns
   const int ngw = pl->Wp >> 2;  // head groups of four: the merge is instantiated for 1, 2 and 4
-  const int lane_n = (ngw == 1 || ngw == 2 || ngw == 4) ? hdp::lane_slots_for(S) : 0;
+  // (S >= 3: the pseudo column that pads the window lists must lose from slot 1 going down AND from slot S going up)
+  const int lane_n = ((ngw == 1 || ngw == 2 || ngw == 4) && S >= 3) ? hdp::lane_slots_for(S) : 0;
   auto lane_ok = [&](int r, int ncols_max) -> bool {
     if (!lane_n) return false;
     const int nm = (r + 63) / 64, np = hdp::kThrThreads / 64 - nm;
@@ -2513,10 +2540,10 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     pl->lane_img_pitch = ip;
     // the lane kernel's own LDS layout: image, census (x2), lean head strips (24 bytes per group and row, pitch
     // kLeanRows), window column lists
-    size_t b = (size_t(cm) * ip * 4 + 15) & ~size_t(15);
+    size_t b = (size_t(cm + 1) * ip * 4 + 15) & ~size_t(15);
     b += 2 * ((size_t(cm) * 4 + 15) & ~size_t(15));
     b += size_t(ngw) * hdp::kLeanRows * 24;
-    b += (size_t(rows) * W * 2 + 15) & ~size_t(15);
+    b += (size_t(rows) * 4 * ngw * 2 + 15) & ~size_t(15);
     pl->lane_lds_bytes = whole ? whole_lds : b;
     if (!whole && (b > kMaxLds || rows > hdp::kLeanRows)) pl->lane = false;
   }
