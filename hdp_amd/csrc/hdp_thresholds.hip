@@ -2044,6 +2044,8 @@ static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t
         if (pd.tier_k < pd.S)
           return launch_thr_persistent(thresholds_lane_kernel<N, 1, true, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
       }
+      if (whole)
+        return launch_thr_persistent(thresholds_lane_kernel<N, 1, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
       return launch_thr_persistent(thresholds_lane_kernel<N, 1, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
     case 2:
       if constexpr (N > 64) {
@@ -2052,6 +2054,8 @@ static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t
         if (pd.tier_k < pd.S)
           return launch_thr_persistent(thresholds_lane_kernel<N, 2, true, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
       }
+      if (whole)
+        return launch_thr_persistent(thresholds_lane_kernel<N, 2, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
       return launch_thr_persistent(thresholds_lane_kernel<N, 2, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
     case 4:
       if constexpr (N > 64) {
@@ -2060,6 +2064,8 @@ static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t
         if (pd.tier_k < pd.S)
           return launch_thr_persistent(thresholds_lane_kernel<N, 4, true, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
       }
+      if (whole)
+        return launch_thr_persistent(thresholds_lane_kernel<N, 4, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
       return launch_thr_persistent(thresholds_lane_kernel<N, 4, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
     default: return set_error(HDP_EUNSUP, "lane-per-column kernel: unsupported window width");
   }
@@ -2114,7 +2120,8 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
     snprintf(buf, sizeof buf,
              "thresholds_lane_kernel<N=%d,NG=%d%s> (one lane per column: register merge-exchange sort; %d merging waves; "
              "%d rows x %d blocks, %zu B LDS%s)",
-             plan->lane_n, plan->Wp >> 2, plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : "", plan->n_merge,
+             plan->lane_n, plan->Wp >> 2,
+             plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : (plan->n_blocks == 1 && plan->RP > hdp::kLeanRows ? ",whole-cell" : ""), plan->n_merge,
              plan->rows_per_block, plan->n_blocks, plan->lane_lds_bytes,
              plan->lane_tier_k < plan->S ? "; top 60 samples of a column in LDS, the rest in a global tail" : "");
   else if (v.pipe)
@@ -2440,16 +2447,20 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   size_t whole_lds = 0;
   {
     const int ngw0 = pl->Wp >> 2;
-    const bool tier_ok = S > 64 && S <= 100 && pl->steps_bot == 0 && (ngw0 == 1 || ngw0 == 2 || ngw0 == 4) &&
-                         pl->opt_lane != 0 && pl->opt_pipe != 0 && opt_rows <= 0 && hdp::env_option("HDP_THR_WHOLE", 1) != 0;
-    if (tier_ok && n_doy <= hdp::kWholeRows && n_doy > hdp::kLeanRows) {
-      int ip = hdp::kTierK + 3;
+    // tiered (more than 64 samples per column: top-side quantiles only, bottom walks would start in the global tail) or
+    // with whole columns in LDS (up to 64 samples: any quantiles)
+    const bool tiered = S > 64;
+    const bool cand = S >= 3 && S <= 100 && (!tiered || pl->steps_bot == 0) && (ngw0 == 1 || ngw0 == 2 || ngw0 == 4) &&
+                      pl->opt_lane != 0 && pl->opt_pipe != 0 && opt_rows <= 0 && hdp::env_option("HDP_THR_WHOLE", 1) != 0;
+    if (cand && n_doy <= hdp::kWholeRows && n_doy > hdp::kLeanRows) {
+      int ip = tiered ? hdp::kTierK + 3 : spad;
       if ((ip & 1) == 0) ++ip;
       size_t b = (size_t(n_doy + 1) * ip * 4 + 15) & ~size_t(15);
       b += 2 * ((size_t(n_doy) * 4 + 15) & ~size_t(15));
       b += size_t(ngw0) * hdp::kWholeRows * 24;
       b += (size_t(n_doy) * 4 * ngw0 * 2 + 15) & ~size_t(15);
-      const int waves = 2 * int((n_doy + 63) / 64);
+      const int n_slots = hdp::lane_slots_for(S);
+      const int waves = int((n_doy + 63) / 64) + (int((n_doy + 63) / 64) + hdp::lane_tasks_per_wave_rt(n_slots) - 1) / hdp::lane_tasks_per_wave_rt(n_slots);
       if (b <= kMaxLds && waves * 64 <= hdp::kWholeThreads) {
         whole = true;
         whole_lds = b;
@@ -2534,7 +2545,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     // draws more than that from one column) and the rest in a global tail: three workgroups per CU instead of two.
     // (only the whole-cell form gains from it: three 5-wave workgroups of the blocked form do not fit a CU's
     // register file side by side, measured)
-    pl->lane_tier_k = whole ? hdp::kTierK : (int32_t)S;
+    pl->lane_tier_k = (whole && S > 64) ? hdp::kTierK : (int32_t)S;
     int ip = pl->lane_tier_k < S ? pl->lane_tier_k + 3 : spad;  // sentinel, samples, marker, sentinel
     if ((ip & 1) == 0) ++ip;
     pl->lane_img_pitch = ip;
