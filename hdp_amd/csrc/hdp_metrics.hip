@@ -914,8 +914,11 @@ struct CPair {  // two definitions' state, one per 16-bit half
   uint32_t hwf, hwn, hwd, cur, last_id;
 };
 
+#ifndef HDP_C16_WAVES
+#define HDP_C16_WAVES 1, 4
+#endif
 template <int NP>
-__global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 4))) void metrics_kernel_cells16(
+__global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(HDP_C16_WAVES))) void metrics_kernel_cells16(
     MetDev md, const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
   constexpr int DG = 2 * NP;
   const int lane = threadIdx.x & 63;
@@ -1532,7 +1535,12 @@ static inline bool one_to_one_pre(int64_t n_thr_cells, int64_t n_cells) { return
 // later hdp_metrics_f32_dev creates nothing)
 static int ensure_plan_streams(const hdp_metrics_plan *plan) {
   if (plan->aux_stream) return HDP_OK;
-  HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream, hipStreamNonBlocking));
+  // the exceedance kernels are the memory-bound half of the pair: on a high-priority stream their workgroups are
+  // dispatched ahead of the state machines' and stream at full rate while those keep the vector units busy
+  int prio_lo = 0, prio_hi = 0;
+  HDP_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  const int64_t want = env_option("HDP_METRICS_PRIO", 1);
+  HDP_HIP_TRY(hipStreamCreateWithPriority(&plan->aux_stream, hipStreamNonBlocking, want > 0 ? prio_hi : (want < 0 ? prio_lo : 0)));
   HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->aux_stream2, hipStreamNonBlocking));
   HDP_HIP_TRY(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
   for (int i = 0; i < 2; ++i) {
@@ -1733,7 +1741,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   const bool pairs = plan->opt_pairs != 0;  // exceed_pairs_kernel (two percentiles per pass) instead of exceed_kernel (four)
   const size_t lds_a = pairs ? ((size_t((md.P + 1) / 2 * 2) * md.n_doy * 4 + 15) & ~size_t(15))
                              : ((size_t((md.P + kQB - 1) / kQB * kQB) * md.n_doy * 4 + 15) & ~size_t(15));
-  const bool short_record = ((md.T + 63) >> 6) <= 64;  // at most two 32-word chunks: use 16-word chunks, all four waves
+  const bool short_record = ((md.T + 63) >> 6) <= 64 || plan->opt_cw == 16;  // at most two 32-word chunks: use 16-word chunks, all four waves
   if (split) {
     HDP_REQUIRE(lds_a <= kLdsPerCU - 1024, HDP_EUNSUP, "too many percentiles for the exceedance kernel");
     const void *ek = pairs ? (short_record ? reinterpret_cast<const void *>(exceed_pairs_kernel<16>)
@@ -1781,7 +1789,8 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
         const int rc = launch_transpose(x_dev + c0, tm_pitch, md.T, nc, const_cast<float *>(x_b), sx);
         if (rc != HDP_OK) return rc;
       }
-      if (pairs && short_record)
+      if (HDP_MDBG(md, 8)) {  // ablation builds: state machines only, on the exceedance words of the previous call
+      } else if (pairs && short_record)
         hipLaunchKernelGGL(exceed_pairs_kernel<16>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
       else if (pairs)
         hipLaunchKernelGGL(exceed_pairs_kernel<32>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
@@ -1795,6 +1804,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
         HDP_HIP_TRY(hipStreamWaitEvent(sm, plan->ev_exceed[half], 0));
       }
     }
+    if (by_cells && HDP_MDBG(md, 16)) continue;  // ablation builds: exceedance words only
     if (by_cells) {
       mb.out_cells = n_cells;  // the device layout is indexed with the series of the whole call
       mb.cell_off = c0;

@@ -762,7 +762,10 @@ __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf
 constexpr int kLeanRows = 128;                       // strip pitch of the blocked form (rows per block <= 128)
 constexpr int kWholeRows = 384;                      // strip pitch of the whole-cell form (all day-of-year rows in one workgroup)
 constexpr int kWholeThreads = 768;                   // 6 merging + 6 producing waves
-constexpr int kTierK = 60;                           // tiered image: samples of a column kept in LDS (plans with S > 64)
+#ifndef HDP_TIERK
+#define HDP_TIERK 60
+#endif
+constexpr int kTierK = HDP_TIERK;                           // tiered image: samples of a column kept in LDS (plans with S > 64)
 constexpr uint32_t kRawMax = 0x7fe00000u;            // above +inf (0x7f800000), finite as the high word of a double
 constexpr uint32_t kRawMin = 0xffe00000u;            // below -inf (0xff800000)
 template <int NG, int ROWS>
@@ -1615,11 +1618,14 @@ constexpr int lane_first_pad_slot(int N) {
 template <int N>
 constexpr int lane_tasks_per_wave() { return N >= 64 ? 1 : (N >= 32 ? 2 : 4); }
 
+#ifndef HDP_WHOLE_MINW
+#define HDP_WHOLE_MINW (ROWS == kWholeRows ? 3 : 4)
+#endif
 // ROWS = strip pitch: kLeanRows (blocks of <= 128 rows, up to 8 waves, two or three workgroups per CU) or kWholeRows (every
 // day-of-year row of a cell in one 12-wave workgroup per CU: no halo columns -- each column is sorted once per cell --
 // and all 365 merge chains of the cell in flight at once)
 template <int N, int NG, bool TIER, int ROWS>
-__global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, ROWS == kWholeRows ? 3 : 4) void thresholds_lane_kernel(ThrDev pd, const float *__restrict__ x,
+__global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, HDP_WHOLE_MINW) void thresholds_lane_kernel(ThrDev pd, const float *__restrict__ x,
                                                                       int64_t n_cells, double *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from hdp_amd import _lib, calendar as cal, core, utils
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+if os.environ.get('HDP_DBG_LIB'):
+    _lib.LIB_PATH = os.environ['HDP_DBG_LIB']
 lib = _lib.ensure_device(0)
 dev = torch.device("cuda", 0)
 sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
@@ -45,4 +47,16 @@ for it in range(3):
         mplan.run(xm.data_ptr(), thr.data_ptr(), n, south_dev.data_ptr(), n, out.data_ptr(), sb.cuda_stream)
         tplan.run(xb.data_ptr(), n, thr2.data_ptr(), sa.cuda_stream)
     t_rev = timed(both_rev)
+    e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize()
+    e0.record(sa); sb.wait_event(e0)
+    tplan.run(xb.data_ptr(), n, thr2.data_ptr(), sa.cuda_stream); ea.record(sa)
+    mplan.run(xm.data_ptr(), thr.data_ptr(), n, south_dev.data_ptr(), n, out.data_ptr(), sb.cuda_stream); eb.record(sb)
+    torch.cuda.synchronize()
+    print(f"   thr-first: thresholds done at {e0.elapsed_time(ea):.2f} ms, metrics done at {e0.elapsed_time(eb):.2f} ms")
+    e0.record(sb); sa.wait_event(e0)
+    mplan.run(xm.data_ptr(), thr.data_ptr(), n, south_dev.data_ptr(), n, out.data_ptr(), sb.cuda_stream); eb.record(sb)
+    tplan.run(xb.data_ptr(), n, thr2.data_ptr(), sa.cuda_stream); ea.record(sa)
+    torch.cuda.synchronize()
+    print(f"   met-first: thresholds done at {e0.elapsed_time(ea):.2f} ms, metrics done at {e0.elapsed_time(eb):.2f} ms")
     print(f"iter {it}: thresholds {t_thr:.2f} ms, metrics {t_met:.2f} ms, sum {t_thr + t_met:.2f}; concurrent (thr first) {t_both:.2f}, (metrics first) {t_rev:.2f}")
