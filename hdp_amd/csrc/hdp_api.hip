@@ -421,6 +421,8 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
                 (long long)t, (long long)doy_map[t], (long long)n_doy);
     dm[t] = (uint16_t)v;
   }
+  bool regular = true;  // doy_map[t] == t mod n_doy: the year-aligned exceedance kernel applies
+  for (int64_t t = 0; t < T && regular; ++t) regular = dm[t] == uint16_t(t % n_doy);
   std::vector<int32_t> dd(D * 3);
   for (int64_t i = 0; i < D * 3; ++i) {
     HDP_REQUIRE(defs[i] > -(int64_t(1) << 30) && defs[i] < (int64_t(1) << 30), HDP_EINVAL,
@@ -453,6 +455,7 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   auto *pl = new hdp_metrics_plan();
   pl->T = T; pl->n_doy = n_doy; pl->D = D; pl->Y = Y; pl->P = P;
   pl->ordered_seasons = ordered;
+  pl->regular_calendar = regular;
   pl->defs_host.assign(defs, defs + D * 3);
   // HDP_METRICS_* selectors: read here, once (tests and A/B runs; every value gives the same results)
   pl->opt_general = env_option("HDP_METRICS_GENERAL", 0) != 0;
@@ -462,6 +465,8 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   pl->opt_overlap = env_option("HDP_METRICS_OVERLAP", 1) != 0;
   pl->opt_pairs = env_option("HDP_METRICS_PAIRS", 1) != 0;
   pl->opt_cw = (int32_t)env_option("HDP_METRICS_CW", 0);
+  pl->opt_years = env_option("HDP_METRICS_YEARS", 1) != 0;
+  pl->opt_years_lds = (int32_t)std::min<long long>(65536, std::max<long long>(0, env_option("HDP_METRICS_YEARS_LDS", 16384)));
   pl->opt_batch = std::max<long long>(0, env_option("HDP_METRICS_BATCH", 0));
   pl->Ypitch = (Y + 15) & ~int64_t(15);  // 32-byte rows: sector-aligned packed stores
   int64_t dmax = 1;
@@ -611,8 +616,9 @@ const char *hdp_metrics_plan_describe(const hdp_metrics_plan *plan) {
   else if (!plan->opt_cells)
     snprintf(buf, sizeof buf, "exceed_kernel + metrics_kernel_uniform (lane = (percentile, definition)) + transpose");
   else
-    snprintf(buf, sizeof buf, "exceed_kernel + metrics_kernel_cells%s (lane = series; batches of series, the two kernels of "
+    snprintf(buf, sizeof buf, "%s + metrics_kernel_cells%s (lane = series; batches of series, the two kernels of "
              "consecutive batches overlap on the plan's streams)",
+             hdp::metrics_year_words(plan) ? "exceed_years_kernel" : (plan->opt_pairs ? "exceed_pairs_kernel" : "exceed_kernel"),
              (plan->defs_fit16 && plan->T <= 65535 && plan->opt_packed) ? "16 (packed 16-bit state)" : "");
   return buf;
 }

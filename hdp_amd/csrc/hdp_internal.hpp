@@ -146,6 +146,7 @@ struct hdp_metrics_plan {
   int64_t Ypitch = 0;
   int64_t dmax = 1;           // max over definitions of max(min_duration, 1)
   bool uniform_seasons = false;  // consecutive seasons >= dmax + 64 days apart (fast kernel)
+  bool regular_calendar = false; // doy_map[t] == t mod n_doy for every t (noleap / 360-day records that start on day 0)
   bool defs_fit16 = false;       // every min_duration and max_break in [0, 16383], max_subs >= 0: packed 16-bit state machines
   hdp::DevBuf doy_map;   // uint16 [T rounded up to 64]
   hdp::DevBuf defs;      // int32 [D][3]
@@ -160,7 +161,7 @@ struct hdp_metrics_plan {
   // split path: the streaming exceedance kernel of batch b+1 runs on a second stream beside the
   // VALU-bound state-machine kernel of batch b (created on first use, owned by the plan)
   // HDP_METRICS_* selectors (testing and A/B only; every value gives the same results), read once at plan creation
-  int32_t opt_general = 0, opt_fused = 0, opt_cells = 1, opt_packed = 1, opt_overlap = 1, opt_pairs = 1, opt_cw = 0;
+  int32_t opt_general = 0, opt_fused = 0, opt_cells = 1, opt_packed = 1, opt_overlap = 1, opt_pairs = 1, opt_cw = 0, opt_years = 1, opt_years_lds = 16384;
   int64_t opt_batch = 0;
   mutable hipStream_t aux_stream = nullptr, aux_stream2 = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_exceed[2] = {nullptr, nullptr}, ev_state[2] = {nullptr, nullptr};
@@ -183,6 +184,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
 int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
                    int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells,
                    int16_t *out_dev, hipStream_t stream, int64_t tm_pitch = 0);
+bool metrics_year_words(const hdp_metrics_plan *plan);  // exceed_years_kernel + year-aligned scratch words apply
 int launch_metrics_any_ranges(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
                               int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells, int16_t *out_dev,
                               hipStream_t stream, int64_t tm_pitch);

@@ -44,6 +44,8 @@ struct MetDev {
   int debug;                               // timing ablations only (HDP_METRICS_DEBUG): 1 = no stage B, 2 = no stage A
   unsigned long long *bits_g;              // split path: exceedance words [cell][P][words_pad] in HBM
   int words_pad;                           // 64-day words per (cell, percentile) row, multiple of kCW
+  int n_words;                             // words of a row that carry data
+  int year_words;                          // 1: year-aligned words (exceed_years_kernel), see there; 0: word w = days [64 w, 64 w + 64)
   long long out_cells, cell_off;           // series count of the whole output / offset of this launch's first series
 };
 
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_general(
   st.acc_f = st.acc_n = st.acc_d = st.acc_a = 0;
 
   const float *xc = x + cell * int64_t(md.T);
-  const int n_words = (md.T + 63) >> 6;
+  const int n_words = md.n_words;
 
   for (int w0 = 0; w0 < n_words; w0 += kChunkWords) {
     const int nw = min(kChunkWords, n_words - w0);
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
   }
   __syncthreads();
   const float *xc = x + cell * int64_t(md.T);
-  const int n_words = (md.T + 63) >> 6;
+  const int n_words = md.n_words;
   const int Tp = n_words * 64;
   unsigned long long *brow = md.bits_g + cell * md.P * int64_t(md.words_pad);
   static_assert(kQB == 4, "one float4 of thresholds per day");
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256) void exceed_pairs_kernel(MetDev md, const floa
   }
   __syncthreads();
   const float *xc = x + cell * int64_t(md.T);
-  const int n_words = (md.T + 63) >> 6;
+  const int n_words = md.n_words;
   const int Tp = n_words * 64;
   unsigned long long *brow = md.bits_g + cell * md.P * int64_t(md.words_pad);
   const uint32_t row_bytes = uint32_t(PP) * 4u;
@@ -439,6 +441,122 @@ __global__ __launch_bounds__(256) void exceed_pairs_kernel(MetDev md, const floa
       }
     }
   }
+}
+
+// ---- exceedance words for REGULAR calendars (doy_map[t] == t mod n_doy, 320 < n_doy <= 384): year-aligned words ---------
+// The scratch row of a (series, percentile) holds kYearSpans = 6 words per year: word 6 y + j covers the 64 days that start
+// at day y n_doy + 64 j.  The last word of a year therefore runs 384 - n_doy days into the next year (19 for a 365-day
+// calendar): those bits repeat the first bits of the next word, and a consumer treats only the first n_doy - 320 bits of
+// it as positions a run can start or end at (metrics_kernel_cells16 does; a run that reaches them continues in the next
+// word).  What this buys: lane L of span j of ANY year is day-of-year (64 j + L) mod n_doy, so the thresholds a lane ever
+// needs are 6 x NP values that stay in its registers for the whole record (f32 rounded toward -inf, as in exceed_kernel),
+// and a span's ballot IS a word of the scratch: no LDS, no day-of-year table, no lane collection.  One wave per series
+// walks the record in time order (the next year's six loads in flight); the ballots of two adjacent spans leave with one
+// s_store_dwordx4 through the scalar data cache (s_dcache_wb before the wave ends; tools/ubench/sstore.hip: correct,
+// 1.3 ns per ballot and CU), the zero words up to the row pitch the same way -- a row never mixes scalar and vector
+// writes.  Vector instructions per series and year: 6 loads + 6 NP compares (exceed_pairs_kernel: ~340 at NP = 10), which
+// is what the state-machine kernel running beside this one is short of.
+typedef unsigned long long hdp_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sstore128(unsigned long long *base, uint32_t byte_off, hdp_u64x2 v) {
+  asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(v), "s"(base), "s"(byte_off) : "memory");
+}
+
+constexpr int kYearSpans = 6;  // words (spans of 64 days) per year: n_doy in (320, 384]
+constexpr int kYearsPG = 10;   // percentiles per launch (6 x NP threshold registers per lane)
+#ifndef HDP_YEARS_AHEAD
+#define HDP_YEARS_AHEAD 5
+#endif
+constexpr int kYearsAhead = HDP_YEARS_AHEAD;  // years of loads in flight per wave
+
+template <int NP>  // percentiles of this launch: [p0, p0 + NP)
+__global__ __launch_bounds__(64) void exceed_years_kernel(MetDev md, const float *__restrict__ x,
+                                                          const double *__restrict__ thr, int64_t n_thr_cells,
+                                                          int64_t n_cells, int p0) {
+  constexpr int NJ = kYearSpans;
+  static_assert(NJ % 2 == 0, "spans leave in pairs");
+  const int lane = threadIdx.x;
+  const int64_t cell = blockIdx.x;
+  const int n_doy = md.n_doy, T = md.T;
+  float th[NJ][NP];
+  {
+    const double *tc = thr + (cell % n_thr_cells) * int64_t(n_doy) * md.P + int64_t(p0) * n_doy;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      int doy = 64 * j + lane;
+      if (doy >= n_doy) doy -= n_doy;  // the last span runs into the next year
+#pragma unroll
+      for (int q = 0; q < NP; ++q) th[j][q] = f64_to_f32_down(tc[int64_t(q) * n_doy + doy]);
+    }
+  }
+  const float *xc = x + cell * int64_t(T);
+  unsigned long long *rows[NP];  // wave-uniform row bases
+#pragma unroll
+  for (int q = 0; q < NP; ++q) rows[q] = md.bits_g + (cell * md.P + p0 + q) * int64_t(md.words_pad);
+  const int n_years = md.n_words / NJ;
+  auto load_year = [&](int y, float (&buf)[NJ]) {  // a year whose six spans lie inside the record
+    const float *xy = xc + y * n_doy + lane;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) buf[j] = xy[64 * j];
+  };
+  uint32_t woff = 0;  // byte offset of the year's first word in a row
+  auto year_words = [&](const float (&v)[NJ]) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {  // row by row: the year's six words of a row are 48 adjacent bytes
+#pragma unroll
+      for (int j = 0; j < NJ; j += 2) {
+        hdp_u64x2 m;
+        m.x = __ballot(v[j] > th[j][q]);
+        m.y = __ballot(v[j + 1] > th[j + 1][q]);
+        sstore128(rows[q], woff + uint32_t(j) * 8u, m);
+      }
+    }
+    woff += uint32_t(NJ) * 8u;
+  };
+  // kYearsAhead + 1 register sets, as many years per trip: the loads of the next kYearsAhead years are in flight while a
+  // year is compared (few resident waves with deep queues: the state machines beside this kernel want the registers)
+  constexpr int NB = kYearsAhead + 1;
+  // leading years whose last span (384 days from the year's start) ends inside the record: unmasked loads
+  const int n_whole = min(n_years, T >= 64 * NJ ? (T - 64 * NJ) / n_doy + 1 : 0);
+  float yb[NB][NJ];
+#pragma unroll
+  for (int k = 0; k < kYearsAhead; ++k)
+    if (k < n_whole) load_year(k, yb[k]);
+  int y = 0;
+  // steady state: every year of a trip issues the loads of the year kYearsAhead later, unconditionally (a conditional
+  // load would make the compiler wait for ALL loads before each compare: it assumes the path with nothing in flight)
+  for (; y + NB - 1 + kYearsAhead < n_whole; y += NB) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      load_year(y + k + kYearsAhead, yb[(k + kYearsAhead) % NB]);
+      year_words(yb[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB + kYearsAhead; ++k) {  // drain: at most NB - 1 + kYearsAhead years
+    if (y + k < n_whole) {
+      if (y + k + kYearsAhead < n_whole) load_year(y + k + kYearsAhead, yb[(k + kYearsAhead) % NB]);
+      year_words(yb[k % NB]);
+    }
+  }
+  for (y = n_whole; y < n_years; ++y) {  // the record ends inside these (at most two) years
+    float v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int t = y * n_doy + 64 * j + lane;
+      v[j] = (t < T) ? xc[t] : -INFINITY;  // past the record: no exceedance (metric.py:27 pads with zeros)
+    }
+    year_words(v);
+  }
+  // zero words up to the row pitch (the state machines look one word ahead); n_words and words_pad are even
+  const uint32_t end_off = uint32_t(md.words_pad) * 8u;
+  hdp_u64x2 zero;
+  zero.x = 0ull;
+  zero.y = 0ull;
+  for (uint32_t o = woff; o < end_off; o += 16u) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) sstore128(rows[q], o, zero);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
 }
 
 template <bool SPLIT>
@@ -543,7 +661,7 @@ __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
   } while (0)
 
   const float *xc = x + cell * int64_t(md.T);
-  const int n_words = (md.T + 63) >> 6;
+  const int n_words = md.n_words;
 
   // run-skip shortcut: usable for 2 <= min_duration <= 32 (the look-ahead is one 32-day word)
   const int my_skip = (min_dur >= 2 && min_dur <= 32) ? min_dur : 1;
@@ -728,7 +846,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
   }
   const int skip = min(mmin, 64);  // look-ahead of the run-skip shortcut is one 64-day word
   const int Y = md.Y, dmax = md.dmax;
-  const int n_words = (md.T + 63) >> 6;
+  const int n_words = md.n_words;
   const int64_t n_total = md.out_cells;          // series of the whole output; this launch starts at md.cell_off
   const int64_t plane = int64_t(Y) * n_total;    // one (metric, percentile, definition) plane
 
@@ -960,7 +1078,9 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
   }
   const int skip = min(mmin, 64);  // look-ahead of the run-skip shortcut is one 64-day word
   const int Y = md.Y, dmax = md.dmax;
-  const int n_words = (md.T + 63) >> 6;
+  const int n_words = md.n_words;
+  // year-aligned words (exceed_years_kernel): the last word of a year has len5 positions, its other bits repeat the next word's
+  const int len5 = md.year_words ? md.n_doy - 64 * (kYearSpans - 1) : 64;
   const int64_t n_total = md.out_cells;
   const int64_t plane = int64_t(Y) * n_total;
 
@@ -1048,8 +1168,15 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
     uint4 pf[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) pf[q] = act ? bline[q] : make_uint4(0, 0, 0, 0);
+    int t_next = 0, jy = 0;
     for (int w = 0; w < n_words; ++w) {
-      const int t0 = w * 64;
+      // geometry of word w (wave-uniform): first day t0, L positions a run can start or end at
+      const int t0 = t_next;
+      const bool short_word = md.year_words && jy == kYearSpans - 1;
+      const int L = short_word ? len5 : 64;
+      t_next += L;
+      jy = (jy == kYearSpans - 1) ? 0 : jy + 1;
+      const unsigned long long vmask = ~0ull >> (64 - L);
       if ((w & 7) == 0) {  // wave-uniform: park the fetched block, request the next one
 #pragma unroll
         for (int q = 0; q < 4; ++q) slot4[q] = pf[q];
@@ -1059,20 +1186,24 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
       }
       while (si < Y && sb + dmax <= t0) finalize(true);  // wave-uniform
       const unsigned long long word = slot8[w & 7];
+      // the day after bit 63 of a short word is bit 64 - L of the next word (bits L.. repeat its first 64 - L bits)
       const unsigned long long nxt =
-          (w & 7) != 7 ? slot8[(w & 7) + 1] : (((unsigned long long)pf[0].y << 32) | pf[0].x);
+          ((w & 7) != 7 ? slot8[(w & 7) + 1] : (((unsigned long long)pf[0].y << 32) | pf[0].x)) >> (64 - L);
       unsigned long long longs = word;
       for (int k = 1; k < skip; ++k) longs &= (word >> k) | (nxt << (64 - k));
+      longs &= vmask;                                   // runs of >= skip days that START in this word
+      const unsigned long long starts = word & vmask;   // hot days at positions of this word
+      const unsigned long long ends = ~word & vmask;    // cool days at positions of this word
       uint32_t any_hw = 0;
 #pragma unroll
       for (int k = 0; k < NP; ++k) any_hw |= st[k].hw;
-      const bool work = open ? (word != ~0ull) : ((any_hw ? word : longs) != 0ull);
+      const bool work = open ? (ends != 0ull) : ((any_hw ? starts : longs) != 0ull);
       if (__ballot(work) == 0) continue;
       const bool may_credit = t0 + 64 > sa;  // wave-uniform; the current season is never one already closed
       int pos = 0;  // < 64 whenever it is used as a shift
       while (true) {
         if (!open) {
-          const unsigned long long r = (any_hw ? word : longs) >> pos;
+          const unsigned long long r = (any_hw ? starts : longs) >> pos;
           if (r == 0) break;
           pos += __builtin_ctzll(r);
           s_open = t0 + pos;
@@ -1081,7 +1212,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
           for (int k = 0; k < NP; ++k) st[k].hw &= ~pk_lt(max_break[k], gap);  // metric.py:48-49
         }
-        const unsigned long long rz = (~word) >> pos;
+        const unsigned long long rz = ends >> pos;
         if (rz == 0) break;  // the run continues into the next word
         pos += __builtin_ctzll(rz);
         const int e = t0 + pos;
@@ -1516,8 +1647,20 @@ __global__ void generate_kernel(float *__restrict__ x, int64_t n_cells, int64_t 
 // ---- launchers -----------------------------------------------------------------------------------
 // series per launch pair of the split path (bounded scratch; multiples of n_thr_cells when
 // ensemble members share thresholds so that `c % n_thr_cells` stays valid inside a batch)
+// Year-aligned exceedance words (exceed_years_kernel -> metrics_kernel_cells16): regular calendar of 321..384 days and the
+// packed series-per-lane state machines (the only consumer that knows the format).
+bool metrics_year_words(const hdp_metrics_plan *plan) {
+  return plan->regular_calendar && plan->opt_years != 0 && plan->n_doy > 64 * (kYearSpans - 1) &&
+         plan->n_doy <= 64 * kYearSpans && plan->uniform_seasons && !plan->opt_general && !plan->opt_fused &&
+         plan->opt_cells != 0 && plan->defs_fit16 && plan->T <= 65535 && plan->opt_packed != 0;
+}
+int64_t metrics_row_words(const hdp_metrics_plan *plan) {  // words of a (series, percentile) row that carry data
+  return metrics_year_words(plan) ? kYearSpans * ((plan->T + plan->n_doy - 1) / plan->n_doy) : (plan->T + 63) >> 6;
+}
+int64_t metrics_row_pitch(const hdp_metrics_plan *plan) { return (metrics_row_words(plan) + kCW - 1) / kCW * kCW; }
+
 int64_t metrics_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells, int64_t n_thr_cells) {
-  const int64_t words_pad = ((((plan->T + 63) >> 6) + kCW - 1) / kCW) * kCW;
+  const int64_t words_pad = metrics_row_pitch(plan);
   const int64_t row_bytes = plan->P * words_pad * 8;
   // the scratch is a double buffer of at most 2 x 4 GiB.  Batches stay as large as that allows: one wave
   // of the state-machine kernel runs for about a millisecond, so a launch needs many waves per slot
@@ -1556,7 +1699,7 @@ int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells) {
     const int rc = ensure_plan_streams(plan);
     if (rc != HDP_OK) return rc;
   }
-  const int64_t words_pad = ((((plan->T + 63) >> 6) + kCW - 1) / kCW) * kCW;
+  const int64_t words_pad = metrics_row_pitch(plan);
   const size_t need = 2 * size_t(metrics_batch_cells(plan, n_cells, n_cells)) * size_t(plan->P) * words_pad * 8;
   if (plan->bits_scratch.bytes < need) {
     hipError_t e = plan->bits_scratch.alloc(need);
@@ -1668,7 +1811,9 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   md.bits_g = nullptr;
   md.out_cells = n_cells;
   md.cell_off = 0;
-  md.words_pad = ((((md.T + 63) >> 6) + kCW - 1) / kCW) * kCW;
+  md.year_words = metrics_year_words(plan) ? 1 : 0;
+  md.n_words = (int)metrics_row_words(plan);
+  md.words_pad = (int)metrics_row_pitch(plan);
   // Paths (same results; tests/test_gpu_parity.py runs them against each other):
   //   split + by_cells  exceed_kernel -> metrics_kernel_cells (default)
   //   split             exceed_kernel -> metrics_kernel_uniform<true>       HDP_METRICS_CELLS=0
@@ -1738,6 +1883,8 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   HDP_REQUIRE(!split || plan->bits_scratch.p, HDP_ENOMEM, "exceedance scratch is not allocated");
   HDP_REQUIRE(by_cells || plan->rows_scratch.p, HDP_ENOMEM, "metrics row scratch is not allocated");
   md.bits_g = plan->bits_scratch.as<unsigned long long>();
+  // regular calendars: year-aligned spans, thresholds in registers, words through the scalar cache (exceed_years_kernel)
+  const bool years = md.year_words != 0;
   const bool pairs = plan->opt_pairs != 0;  // exceed_pairs_kernel (two percentiles per pass) instead of exceed_kernel (four)
   const size_t lds_a = pairs ? ((size_t((md.P + 1) / 2 * 2) * md.n_doy * 4 + 15) & ~size_t(15))
                              : ((size_t((md.P + kQB - 1) / kQB * kQB) * md.n_doy * 4 + 15) & ~size_t(15));
@@ -1790,6 +1937,19 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
         if (rc != HDP_OK) return rc;
       }
       if (HDP_MDBG(md, 8)) {  // ablation builds: state machines only, on the exceedance words of the previous call
+      } else if (years) {
+        HDP_REQUIRE(nc < (int64_t(1) << 31), HDP_EUNSUP, "too many series for one launch");
+        for (int q0 = 0; q0 < md.P; q0 += kYearsPG) {  // groups of at most kYearsPG percentiles (threshold registers)
+          const dim3 g((unsigned)nc), t(64);
+          const size_t ballast = (size_t)plan->opt_years_lds;  // unused LDS per wave: caps the resident waves (A/B knob)
+          switch (std::min(kYearsPG, md.P - q0)) {
+#define HDP_YEARS_CASE(N) case N: hipLaunchKernelGGL(exceed_years_kernel<N>, g, t, ballast, sx, mb, x_b, thr_b, ntc_b, nc, q0); break;
+            HDP_YEARS_CASE(1) HDP_YEARS_CASE(2) HDP_YEARS_CASE(3) HDP_YEARS_CASE(4) HDP_YEARS_CASE(5)
+            HDP_YEARS_CASE(6) HDP_YEARS_CASE(7) HDP_YEARS_CASE(8) HDP_YEARS_CASE(9)
+            default: hipLaunchKernelGGL(exceed_years_kernel<kYearsPG>, g, t, ballast, sx, mb, x_b, thr_b, ntc_b, nc, q0); break;
+#undef HDP_YEARS_CASE
+          }
+        }
       } else if (pairs && short_record)
         hipLaunchKernelGGL(exceed_pairs_kernel<16>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
       else if (pairs)

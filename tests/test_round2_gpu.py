@@ -189,3 +189,70 @@ def test_comm_of_one_rank_allgathers_in_place():
     finally:
         hdist.comm_destroy()
     assert not hdist.comm_ready()
+
+
+def _regular_case(seed, n_doy, T, n, P, defs, long_runs):
+    """A record on a REGULAR calendar (doy_map[t] = t mod n_doy), seasons given per year; hot spells across year ends."""
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 1, size=(n, T)).astype(np.float32)
+    if long_runs:
+        for s in range(n):
+            for _ in range(6):   # hot spells of 5..90 days, some across a year end and across the record's end
+                a = int(rng.integers(0, T))
+                if rng.random() < 0.5:
+                    a = int(rng.integers(1, max(2, T // n_doy + 1))) * n_doy - int(rng.integers(1, 30))
+                x[s, max(a, 0): a + int(rng.integers(5, 90))] = 9.0
+        x[0, T - 70:] = 9.0                # open at the end of the record
+        x[1 % n, : min(T, 400)] = 9.0      # a run longer than a year's first words
+    thr = np.sort(rng.normal(0.7, 0.4, size=(n, n_doy, P)), axis=2)
+    doy_map = np.arange(T, dtype=np.int64) % n_doy
+    years = (T + n_doy - 1) // n_doy
+    north = np.array([[y * n_doy + 120, min(T, y * n_doy + 273)] for y in range(years) if y * n_doy + 120 < T])
+    south = np.array([[y * n_doy + 304, min(T, (y + 1) * n_doy + 90)] for y in range(years) if y * n_doy + 304 < T])
+    Y = min(len(north), len(south))
+    is_south = (np.arange(n) % 3 == 1).astype(np.uint8)
+    return x, thr, doy_map, defs, north[:Y], south[:Y], is_south
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_doy,T,P,defs", [
+    (365, 365 * 9, 10, [[3, 0, 0], [3, 1, 1], [4, 0, 0], [4, 1, 1], [5, 0, 0], [5, 1, 1]]),   # whole years
+    (365, 365 * 9 + 1, 3, [[3, 0, 0], [2, 1, 1]]),          # one day of a tenth year
+    (365, 365 * 8 + 330, 13, [[3, 1, 2], [6, 2, 0]]),        # two percentile groups (10 + 3); last span of the partial year
+    (365, 365 * 8 + 64, 1, [[1, 0, 0], [0, 3, 1]]),          # exactly one word of the last year
+    (365, 365 * 8 + 63, 2, [[25, 1, 1], [30, 0, 0]]),        # min_duration beyond the 19 repeated days of a short word
+    (360, 360 * 7 + 200, 4, [[3, 0, 0], [40, 2, 1]]),        # 360-day calendar: 40-day last word
+    (366, 366 * 6, 5, [[3, 1, 1], [22, 0, 0]]),
+    (321, 321 * 7 + 5, 2, [[3, 0, 0], [2, 1, 1]]),           # one-day last word, 63 repeated days
+    (384, 384 * 6 + 100, 3, [[3, 0, 0], [64, 1, 1]]),        # six full words per year, nothing repeated
+])
+def test_year_aligned_exceedance_words_match_the_oracle_and_the_day_aligned_path(n_doy, T, P, defs, monkeypatch):
+    """exceed_years_kernel (regular calendars; six words per year, the last one running into the next year, thresholds in
+    registers, words through the scalar cache) + the state machines reading that format: against the C oracle and against
+    the day-aligned exceed_pairs_kernel path (HDP_METRICS_YEARS=0), 70 series (a ragged second wave), hot spells across
+    year ends and the end of the record."""
+    case = _regular_case(4000 + n_doy + P, n_doy, T, 70, P, defs, long_runs=True)
+    x, thr, doy_map, dfs, north, south, is_south = case
+    plan = core.MetricsPlan(doy_map, n_doy, dfs, north, south, P)
+    assert "exceed_years_kernel" in plan.describe()
+    want = c_oracle.metrics(x, thr, doy_map, dfs, north, south, is_south)
+    got = core.compute_heatwave_metrics(*case)
+    assert np.array_equal(got.astype(np.int64), want)
+    monkeypatch.setenv("HDP_METRICS_BATCH", "32")    # three batches: the double-buffered scratch in the new format
+    assert np.array_equal(core.compute_heatwave_metrics(*case), got)
+    monkeypatch.delenv("HDP_METRICS_BATCH")
+    monkeypatch.setenv("HDP_METRICS_YEARS", "0")
+    plan0 = core.MetricsPlan(doy_map, n_doy, dfs, north, south, P)
+    assert "exceed_years_kernel" not in plan0.describe()
+    assert np.array_equal(core.compute_heatwave_metrics(*case), got)
+
+
+@pytest.mark.gpu
+def test_irregular_calendars_keep_the_day_aligned_words():
+    """A leap-year calendar (doy_map is not t mod n_doy) must not take the year-aligned path."""
+    dates = utils.noleap_date_range("2000-01-01", "2003-12-31")
+    doy_map = cal.build_doy_map(dates).copy()
+    doy_map[500:] = (doy_map[500:] + 1) % 365     # a shifted calendar from day 500 on
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    plan = core.MetricsPlan(doy_map, 365, [[3, 0, 0]], north, south, 2)
+    assert "exceed_years_kernel" not in plan.describe()
