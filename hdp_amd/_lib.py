@@ -55,6 +55,7 @@ SIGNATURES = {
     "hdp_metrics_plan_destroy": (C.c_int, [vp]),
     "hdp_metrics_year_pitch": (i64, [vp]),
     "hdp_metrics_plan_reserve": (C.c_int, [vp, i64]),
+    "hdp_metrics_plan_batch_cells": (i64, [vp, i64]),
     "hdp_metrics_f32_dev": (C.c_int, [vp, vp, vp, i64, vp, i64, vp, vp]),
     "hdp_metrics_f32": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, vp]),
     "hdp_metrics_f32_planes_i64": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, vp]),

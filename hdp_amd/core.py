@@ -287,6 +287,10 @@ class MetricsPlan:
         """Allocate the exceedance scratch up front (keeps run() free of allocations)."""
         _lib.check(self.lib.hdp_metrics_plan_reserve(self.handle, int(n_cells)))
 
+    def batch_cells(self, n_cells):
+        """Series per batch of the split path for a call of n_cells series."""
+        return int(self.lib.hdp_metrics_plan_batch_cells(self.handle, int(n_cells)))
+
     def run(self, x_ptr, thr_ptr, n_thr_cells, is_south_ptr, n_cells, out_ptr, stream=None):
         """Device pointers; thr is [n_thr_cells][P][n_doy] float64 as written by ThresholdPlan.run."""
         _lib.check(self.lib.hdp_metrics_f32_dev(self.handle, x_ptr, thr_ptr, int(n_thr_cells), is_south_ptr,

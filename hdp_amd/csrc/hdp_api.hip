@@ -507,6 +507,11 @@ int hdp_metrics_plan_reserve(hdp_metrics_plan *plan, int64_t n_cells) {
   return reserve_metrics_scratch(plan, n_cells);
 }
 
+int64_t hdp_metrics_plan_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells) {
+  if (!plan || n_cells <= 0) return 0;
+  return metrics_batch_cells(plan, n_cells, n_cells);
+}
+
 int hdp_metrics_f32_dev(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
                         int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells,
                         int16_t *out_dev, void *stream) {

@@ -192,6 +192,7 @@ int launch_metrics_any_ranges(const hdp_metrics_plan *plan, const float *x_dev, 
 int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, int64_t pitch, int64_t n_cells,
                          double *out_dev, hipStream_t stream);
 int reserve_metrics_scratch(const hdp_metrics_plan *plan, int64_t n_cells);
+int64_t metrics_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells, int64_t n_thr_cells);
 int launch_table_percentiles(const float *x_dev, int64_t n_cells, int64_t T, const int64_t *win_dev,
                              int64_t n_doy, int64_t B, const QuantileParam *qp_dev,
                              const int32_t *klo_dev, const int32_t *khi_dev, int64_t P,

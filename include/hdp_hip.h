@@ -142,6 +142,8 @@ int hdp_metrics_plan_destroy(hdp_metrics_plan *plan);
  * allocated on first use; call this once up front to keep hdp_metrics_f32_dev free of
  * allocations (stream capture, latency-sensitive callers).  Not thread-safe per plan. */
 int hdp_metrics_plan_reserve(hdp_metrics_plan *plan, int64_t n_cells);
+/* Series per batch of the split path for a call of n_cells series (n_cells itself when the call is one batch). */
+int64_t hdp_metrics_plan_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells);
 /* Years (seasons) per series in the device output: the Y of the plan.  Kept for sizing the output
  * buffer: 4 * P * D * hdp_metrics_year_pitch(plan) * n_cells int16 elements. */
 int64_t hdp_metrics_year_pitch(const hdp_metrics_plan *plan);
