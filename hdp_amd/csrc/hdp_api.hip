@@ -465,7 +465,7 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   pl->opt_overlap = env_option("HDP_METRICS_OVERLAP", 1) != 0;
   pl->opt_pairs = env_option("HDP_METRICS_PAIRS", 1) != 0;
   pl->opt_cw = (int32_t)env_option("HDP_METRICS_CW", 0);
-  pl->opt_years = env_option("HDP_METRICS_YEARS", 1) != 0;
+  pl->opt_years = (int32_t)env_option("HDP_METRICS_YEARS", 1);   // 0: never, 1: records of >= 24 years, 2: any length
   pl->opt_years_lds = (int32_t)std::min<long long>(65536, std::max<long long>(0, env_option("HDP_METRICS_YEARS_LDS", 16384)));
   pl->opt_batch = std::max<long long>(0, env_option("HDP_METRICS_BATCH", 0));
   pl->Ypitch = (Y + 15) & ~int64_t(15);  // 32-byte rows: sector-aligned packed stores

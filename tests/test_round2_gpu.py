@@ -225,12 +225,15 @@ def _regular_case(seed, n_doy, T, n, P, defs, long_runs):
     (366, 366 * 6, 5, [[3, 1, 1], [22, 0, 0]]),
     (321, 321 * 7 + 5, 2, [[3, 0, 0], [2, 1, 1]]),           # one-day last word, 63 repeated days
     (384, 384 * 6 + 100, 3, [[3, 0, 0], [64, 1, 1]]),        # six full words per year, nothing repeated
+    (365, 365 * 40 + 17, 10, [[3, 0, 0], [3, 1, 1], [5, 2, 2]]),  # 40 years: the steady-state loop with five years of loads in flight
+    (365, 365 * 31, 2, [[4, 1, 1]]),
 ])
 def test_year_aligned_exceedance_words_match_the_oracle_and_the_day_aligned_path(n_doy, T, P, defs, monkeypatch):
     """exceed_years_kernel (regular calendars; six words per year, the last one running into the next year, thresholds in
     registers, words through the scalar cache) + the state machines reading that format: against the C oracle and against
     the day-aligned exceed_pairs_kernel path (HDP_METRICS_YEARS=0), 70 series (a ragged second wave), hot spells across
     year ends and the end of the record."""
+    monkeypatch.setenv("HDP_METRICS_YEARS", "2")     # also for records shorter than 24 years
     case = _regular_case(4000 + n_doy + P, n_doy, T, 70, P, defs, long_runs=True)
     x, thr, doy_map, dfs, north, south, is_south = case
     plan = core.MetricsPlan(doy_map, n_doy, dfs, north, south, P)
