@@ -1671,6 +1671,9 @@ int64_t metrics_batch_cells(const hdp_metrics_plan *plan, int64_t n_cells, int64
   // of the state-machine kernel runs for about a millisecond, so a launch needs many waves per slot
   // (8192 series per launch cost +20 % in tail effects)
   int64_t batch = std::max<int64_t>(1, (int64_t(4) << 30) / row_bytes);
+  // calls that would be one or two batches (an 8-GPU shard of C3: 129 600 series) are cut into four, but not below
+  // 32 768 series: the first batch's exceedance kernel has nothing to run beside (20.0 -> 19.5 ms at 129 600 series)
+  batch = std::min(batch, std::max<int64_t>(32768, (n_cells + 3) / 4));
   if (plan->opt_batch > 0) batch = plan->opt_batch;
   if (n_thr_cells != n_cells && batch < n_cells)
     batch = std::max<int64_t>(n_thr_cells, batch / n_thr_cells * n_thr_cells);
