@@ -468,6 +468,7 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   pl->opt_years = (int32_t)env_option("HDP_METRICS_YEARS", 1);   // 0: never, 1: records of >= 24 years, 2: any length
   pl->opt_years_lds = (int32_t)std::min<long long>(65536, std::max<long long>(0, env_option("HDP_METRICS_YEARS_LDS", 16384)));
   pl->opt_batch = std::max<long long>(0, env_option("HDP_METRICS_BATCH", 0));
+  pl->opt_simple = env_option("HDP_METRICS_SIMPLE", 1) != 0;   // short path for pairs of definitions with max_break = 0
   pl->Ypitch = (Y + 15) & ~int64_t(15);  // 32-byte rows: sector-aligned packed stores
   int64_t dmax = 1;
   for (int64_t d = 0; d < D; ++d) dmax = std::max<int64_t>(dmax, dd[3 * d]);
@@ -484,6 +485,19 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   pl->defs_fit16 = fit16;
   hipError_t e = pl->doy_map.upload(dm.data(), dm.size() * 2);
   if (e == hipSuccess) e = pl->defs.upload(dd.data(), dd.size() * 4);
+  {  // the packed state machines pair definitions two by two: those with max_break = 0 first (stable), so that they pair up
+    std::vector<int32_t> perm, d16(dd.size());
+    for (int pass = 0; pass < 2; ++pass)
+      for (int64_t d = 0; d < D; ++d)
+        if ((dd[3 * d + 1] == 0) == (pass == 0)) perm.push_back((int32_t)d);
+    if (env_option("HDP_METRICS_SIMPLE", 1) == 0)
+      for (int64_t d = 0; d < D; ++d) perm[d] = (int32_t)d;
+    for (int64_t i = 0; i < D; ++i)
+      for (int c = 0; c < 3; ++c) d16[3 * i + c] = dd[3 * perm[i] + c];
+    pl->defs16_host = d16;
+    if (e == hipSuccess) e = pl->defs16.upload(d16.data(), d16.size() * 4);
+    if (e == hipSuccess) e = pl->def_perm.upload(perm.data(), perm.size() * 4);
+  }
   if (e == hipSuccess) e = pl->seasons.upload(ss.data(), ss.size() * sizeof(int2));
   if (e == hipSuccess) e = pl->ranges64.upload(r64.data(), r64.size() * 8);
   if (e != hipSuccess) {

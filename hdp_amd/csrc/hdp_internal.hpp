@@ -150,6 +150,8 @@ struct hdp_metrics_plan {
   bool defs_fit16 = false;       // every min_duration and max_break in [0, 16383], max_subs >= 0: packed 16-bit state machines
   hdp::DevBuf doy_map;   // uint16 [T rounded up to 64]
   hdp::DevBuf defs;      // int32 [D][3]
+  hdp::DevBuf defs16;    // int32 [D][3]: the same definitions, those with max_break = 0 first (packed state machines)
+  hdp::DevBuf def_perm;  // int32 [D]: position in defs16 -> index in defs
   hdp::DevBuf seasons;   // int2 [2][Y]  (north, south)
   mutable hdp::DevBuf bits_scratch;  // split path: exceedance words of two batches of series (double buffer)
   mutable hdp::DevBuf rows_scratch;  // (percentile, definition)-per-lane kernels: [4][P][D][batch][Ypitch] int16
@@ -158,10 +160,11 @@ struct hdp_metrics_plan {
   bool ordered_seasons = true;
   hdp::DevBuf ranges64;              // int64 [2][Y][2] north then south, as given (any order, may overlap)
   std::vector<int64_t> defs_host;    // [D][3]
+  std::vector<int32_t> defs16_host;  // [D][3] in the order of defs16
   // split path: the streaming exceedance kernel of batch b+1 runs on a second stream beside the
   // VALU-bound state-machine kernel of batch b (created on first use, owned by the plan)
   // HDP_METRICS_* selectors (testing and A/B only; every value gives the same results), read once at plan creation
-  int32_t opt_general = 0, opt_fused = 0, opt_cells = 1, opt_packed = 1, opt_overlap = 1, opt_pairs = 1, opt_cw = 0, opt_years = 1, opt_years_lds = 16384;
+  int32_t opt_general = 0, opt_fused = 0, opt_cells = 1, opt_packed = 1, opt_overlap = 1, opt_pairs = 1, opt_cw = 0, opt_years = 1, opt_years_lds = 16384, opt_simple = 1;
   int64_t opt_batch = 0;
   mutable hipStream_t aux_stream = nullptr, aux_stream2 = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_exceed[2] = {nullptr, nullptr}, ev_state[2] = {nullptr, nullptr};

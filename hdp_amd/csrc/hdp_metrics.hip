@@ -47,6 +47,7 @@ struct MetDev {
   int n_words;                             // words of a row that carry data
   int year_words;                          // 1: year-aligned words (exceed_years_kernel), see there; 0: word w = days [64 w, 64 w + 64)
   long long out_cells, cell_off;           // series count of the whole output / offset of this launch's first series
+  const int32_t *def_perm;                 // packed state machines: position in `defs` -> definition index of the output (or null)
 };
 
 constexpr int kMetWaves = 4;
@@ -1036,19 +1037,16 @@ struct CPair {  // two definitions' state, one per 16-bit half
 #ifndef HDP_C16_WAVES
 #define HDP_C16_WAVES 1, 4
 #endif
-template <int NP>
+template <int NP, int NS>  // NP pairs of definitions per lane, the first NS of them "simple" (see below)
 __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(HDP_C16_WAVES))) void metrics_kernel_cells16(
-    MetDev md, const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out) {
-  constexpr int DG = 2 * NP;
+    MetDev md, const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out, int d0) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n_dpass = (md.D + DG - 1) / DG;
   const int64_t n_grp = (n_cells + 63) >> 6;
-  const int64_t task = int64_t(blockIdx.x) * kMetWaves + wave;
-  if (task >= n_grp * md.P * n_dpass) return;  // no workgroup barriers in this kernel
-  const int d0 = int(task % n_dpass) * DG;
-  const int p = int((task / n_dpass) % md.P);
-  const int64_t cell = (task / (int64_t(n_dpass) * md.P)) * 64 + lane;
+  const int64_t task = int64_t(blockIdx.x) * kMetWaves + wave;  // (64 series, percentile); definitions [d0, d0 + DG)
+  if (task >= n_grp * md.P) return;  // no workgroup barriers in this kernel
+  const int p = int(task % md.P);
+  const int64_t cell = (task / md.P) * 64 + lane;
   const bool valid = cell < n_cells;
   const int my_hemi = valid ? int(is_south[cell]) : 2;
   const unsigned long long *brow = md.bits_g + ((valid ? cell : 0) * md.P + p) * int64_t(md.words_pad);
@@ -1077,6 +1075,11 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
     }
     min_dur[k] = a; max_break[k] = b; max_subs[k] = c;
   }
+  // A definition with max_break = 0 ends its heatwave at every gap (metric.py:48-49: a gap is >= 1 day), so it never has a
+  // sub-event, every labelled run is a heatwave of its own and no state crosses a gap: a pair of two such definitions
+  // keeps only its three season sums and costs 6 instead of 22 instructions per run.  The host orders such definitions
+  // first and instantiates the kernel with NS = the number of leading pairs made of them (a compile-time property: as
+  // a run-time flag per pair it cost more scalar work than it saved).
   const int skip = min(mmin, 64);  // look-ahead of the run-skip shortcut is one 64-day word
   const int Y = md.Y, dmax = md.dmax;
   const int n_words = md.n_words;
@@ -1118,6 +1121,15 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
       for (int k = 0; k < NP; ++k) {
         CPair &c = st[k];
         const uint32_t ge = ~pk_lt(len, min_dur[k]);
+        if (k < NS) {  // hw, subs, id, cur, last_id of such a pair are never touched (hw stays 0)
+          if (days > 0) {
+            const uint32_t dd = pk_dup(days) & ge;
+            c.hwf = pk_add(c.hwf, dd);
+            c.hwn = pk_sub(c.hwn, ge);  // ge is -1 per half: += 1
+            c.hwd = pk_max(c.hwd, dd);
+          }
+          continue;
+        }
         const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
         const uint32_t label = sub | ge;
         c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), c.subs & ~c.hw);
@@ -1133,7 +1145,12 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         CPair &c = st[k];
-        if (pre) {
+        if (pre && k < NS) {
+          const uint32_t dd = pk_dup(pre_days);
+          c.hwf = pk_add(c.hwf, dd);
+          c.hwn = pk_add(c.hwn, 0x00010001u);
+          c.hwd = pk_max(c.hwd, dd);
+        } else if (pre) {
           // a run still open dmax days past the season's end is labelled in every branch of the reference
           const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
           credit_k(c, 0xffffffffu, pk_sub(c.id, ~sub), pre_days);  // id + 1 unless it continues as a sub-event
@@ -1145,7 +1162,8 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
             const unsigned hwf = (c.hwf >> (16 * hlf)) & 0xffffu, hwn = (c.hwn >> (16 * hlf)) & 0xffffu;
             const unsigned hwd = (c.hwd >> (16 * hlf)) & 0xffffu;
             const unsigned hwa = hwn ? hwf / hwn : 0u;  // == HWF // HWN
-            int16_t *o = out + ((int64_t(p) * md.D + d) * Y + si) * n_total + md.cell_off + cell;
+            const int dout = md.def_perm ? md.def_perm[d] : d;
+            int16_t *o = out + ((int64_t(p) * md.D + dout) * Y + si) * n_total + md.cell_off + cell;
             const int64_t mstride = int64_t(md.P) * md.D * plane;
             o[0] = (int16_t)hwf;
             o[mstride] = (int16_t)hwn;
@@ -1211,7 +1229,8 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
           open = 1;
           const uint32_t gap = pk_dup(min(s_open - e_prev, 32767));  // >= 1
 #pragma unroll
-          for (int k = 0; k < NP; ++k) st[k].hw &= ~pk_lt(max_break[k], gap);  // metric.py:48-49
+          for (int k = 0; k < NP; ++k)
+            if (k >= NS) st[k].hw &= ~pk_lt(max_break[k], gap);  // metric.py:48-49
         }
         const unsigned long long rz = ends >> pos;
         if (rz == 0) break;  // the run continues into the next word
@@ -1817,6 +1836,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   md.debug = 0;
 #endif
   md.bits_g = nullptr;
+  md.def_perm = nullptr;
   md.out_cells = n_cells;
   md.cell_off = 0;
   md.year_words = metrics_year_words(plan) ? 1 : 0;
@@ -1983,10 +2003,30 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
       const dim3 g((unsigned)blocks), t(kMetWaves * 64);
       const size_t lds_c = size_t(kMetWaves) * 64 * kSlotPitch;
       if (pk_ok) {
-        switch (dg) {
-          case 2: hipLaunchKernelGGL(metrics_kernel_cells16<1>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
-          case 4: hipLaunchKernelGGL(metrics_kernel_cells16<2>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
-          default: hipLaunchKernelGGL(metrics_kernel_cells16<3>, g, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev); break;
+        mb.defs = plan->defs16.as<int32_t>();       // definitions with max_break = 0 first
+        mb.def_perm = plan->def_perm.as<int32_t>();
+        // one launch per pass of dg definitions, instantiated for the number of leading all-simple pairs of that pass
+        const int64_t tasks16 = ((nc + 63) / 64) * md.P;
+        const dim3 g16((unsigned)((tasks16 + kMetWaves - 1) / kMetWaves));
+        for (int d0 = 0; d0 < md.D; d0 += dg) {
+          int ns = 0;
+          while (plan->opt_simple && ns < dg / 2 && d0 + 2 * ns < md.D &&
+                 plan->defs16_host[3 * (d0 + 2 * ns) + 1] == 0 &&
+                 (d0 + 2 * ns + 1 >= md.D || plan->defs16_host[3 * (d0 + 2 * ns + 1) + 1] == 0))
+            ++ns;
+#define HDP_C16_CASE(NPV, NSV) hipLaunchKernelGGL((metrics_kernel_cells16<NPV, NSV>), g16, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev, d0)
+          switch (dg * 4 + ns) {
+            case 2 * 4 + 0: HDP_C16_CASE(1, 0); break;
+            case 2 * 4 + 1: HDP_C16_CASE(1, 1); break;
+            case 4 * 4 + 0: HDP_C16_CASE(2, 0); break;
+            case 4 * 4 + 1: HDP_C16_CASE(2, 1); break;
+            case 4 * 4 + 2: HDP_C16_CASE(2, 2); break;
+            case 6 * 4 + 0: HDP_C16_CASE(3, 0); break;
+            case 6 * 4 + 1: HDP_C16_CASE(3, 1); break;
+            case 6 * 4 + 2: HDP_C16_CASE(3, 2); break;
+            default: HDP_C16_CASE(3, 3); break;
+          }
+#undef HDP_C16_CASE
         }
       } else
       switch (dg) {
