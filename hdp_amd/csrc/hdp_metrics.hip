@@ -1116,7 +1116,19 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
     // one finished run [s, e): reference state machine + season credit, for every definition of the pass
     auto close_run = [&](int s, int e, bool may_credit) {
       const uint32_t len = pk_dup(min(e - s, 32767));
-      const int days = may_credit ? min(e, sb) - max(s, sa) : 0;
+      if (!may_credit) {  // wave-uniform: the word ends before the current season starts -- state only, simple pairs nothing
+#pragma unroll
+        for (int k = NS; k < NP; ++k) {
+          CPair &c = st[k];
+          const uint32_t ge = ~pk_lt(len, min_dur[k]);
+          const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
+          c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), c.subs & ~c.hw);
+          c.id = pk_sub(c.id, ge & ~sub);
+          c.hw = sub | ge;
+        }
+        return;
+      }
+      const int days = min(e, sb) - max(s, sa);
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         CPair &c = st[k];
