@@ -24,7 +24,7 @@ x = torch.empty(n * T, dtype=torch.float32, device=dev)
 lat = torch.linspace(-60, 60, n, device=dev)
 _lib.check(lib.hdp_generate_series_dev(x.data_ptr(), n, T, 0, lat.data_ptr(), 0, 0.7, 0.0, stream))
 out = torch.empty(n * 365 * q.size, dtype=torch.float64, device=dev)
-for it in range(4):
+for it in range(8):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     plan.run(x.data_ptr(), n, out.data_ptr(), stream)
