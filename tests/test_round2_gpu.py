@@ -227,6 +227,8 @@ def _regular_case(seed, n_doy, T, n, P, defs, long_runs):
     (384, 384 * 6 + 100, 3, [[3, 0, 0], [64, 1, 1]]),        # six full words per year, nothing repeated
     (365, 365 * 40 + 17, 10, [[3, 0, 0], [3, 1, 1], [5, 2, 2]]),  # 40 years: the steady-state loop with five years of loads in flight
     (365, 365 * 31, 2, [[4, 1, 1]]),
+    (365, 500, 11, [[3, 0, 0], [2, 1, 1], [1, 0, 0]]),        # a year and a bit; 10 + 1 percentiles; an odd number of simple definitions
+    (365, 365 * 26, 4, [[3, 0, 0], [4, 0, 0], [5, 0, 0], [6, 0, 0]]),  # every pair simple
 ])
 def test_year_aligned_exceedance_words_match_the_oracle_and_the_day_aligned_path(n_doy, T, P, defs, monkeypatch):
     """exceed_years_kernel (regular calendars; six words per year, the last one running into the next year, thresholds in
