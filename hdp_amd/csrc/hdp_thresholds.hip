@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
       rf.n_neg += f & 0x7fff;
       base[j] = c * pd.S_pad;
       lo[j] = 0;
-      hi[j] = (j < W) ? S : 0;
+      hi[j] = (j < W) ? min(S, R) : 0;  // no column holds more than the R keys ranked above the wanted one
     }
     if (nan_or >> 31) rf.n_pos = -1;
 
