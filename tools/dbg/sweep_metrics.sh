@@ -5,11 +5,9 @@ import json
 d=json.loads(open('gpurun_out/r02/sw_$tag.json').read().strip().split('\n')[-1])
 print('$tag', round(d['ms_per_step'],1), round(d['kernels']['thresholds_kernel']['ms_per_launch'],1), round(d['kernels']['metrics_kernel']['ms_per_launch'],1))
 "; }
-L=hdp_amd/libhdp_a5.so
-run a5lds20 HDP_DBG_LIB=$L HDP_METRICS_YEARS_LDS=20480
-run a5lds16 HDP_DBG_LIB=$L HDP_METRICS_YEARS_LDS=16384
-run a5lds24 HDP_DBG_LIB=$L HDP_METRICS_YEARS_LDS=24576
-run a5lds20b48 HDP_DBG_LIB=$L HDP_METRICS_YEARS_LDS=20480 HDP_METRICS_BATCH=49152
-run a5lds20b64 HDP_DBG_LIB=$L HDP_METRICS_YEARS_LDS=20480 HDP_METRICS_BATCH=65536
-run a5lds20b40 HDP_DBG_LIB=$L HDP_METRICS_YEARS_LDS=20480 HDP_METRICS_BATCH=40960
-run a5lds28b48 HDP_DBG_LIB=$L HDP_METRICS_YEARS_LDS=28672 HDP_METRICS_BATCH=49152
+run base X=1
+run lds12 HDP_METRICS_YEARS_LDS=12288
+run lds20 HDP_METRICS_YEARS_LDS=20480
+run b64 HDP_METRICS_BATCH=65536
+run b48 HDP_METRICS_BATCH=49152
+run b128 HDP_METRICS_BATCH=131072

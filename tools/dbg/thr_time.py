@@ -9,15 +9,16 @@ if os.environ.get('HDP_DBG_LIB'):
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 years = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+members = int(sys.argv[3]) if len(sys.argv) > 3 else 1     # C5: 10 members appended along time (S = members * years)
 lib = _lib.ensure_device(0)
 dev = torch.device("cuda", 0)
 ts = torch.cuda.Stream(dev)
 torch.cuda.set_stream(ts)
 stream = ts.cuda_stream
-T = years * 365
+T = years * 365 * members
 dates = utils.noleap_date_range("2000-01-01", f"{2000 + years - 1}-12-31")
-ti, cols = cal.window_columns(dates, 7)
-q = np.arange(0.9, 1.0, 0.01)
+ti, cols = cal.window_columns(np.concatenate([dates] * members), 7)
+q = np.arange(0.9, 1.0, 0.01) if members == 1 else np.linspace(0.80, 0.99, 20)
 plan = core.ThresholdPlan(ti, cols, q, T)
 print(plan.describe() if hasattr(plan, "describe") else "")
 x = torch.empty(n * T, dtype=torch.float32, device=dev)
