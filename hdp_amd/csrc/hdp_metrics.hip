@@ -1035,7 +1035,7 @@ struct CPair {  // two definitions' state, one per 16-bit half
 };
 
 #ifndef HDP_C16_WAVES
-#define HDP_C16_WAVES 1, 4
+#define HDP_C16_WAVES 1, 5
 #endif
 template <int NP, int NS>  // NP pairs of definitions per lane, the first NS of them "simple" (see below)
 __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(HDP_C16_WAVES))) void metrics_kernel_cells16(

@@ -6,8 +6,7 @@ d=json.loads(open('gpurun_out/r02/sw_$tag.json').read().strip().split('\n')[-1])
 print('$tag', round(d['ms_per_step'],1), round(d['kernels']['thresholds_kernel']['ms_per_launch'],1), round(d['kernels']['metrics_kernel']['ms_per_launch'],1))
 "; }
 run base X=1
-run lds12 HDP_METRICS_YEARS_LDS=12288
-run lds20 HDP_METRICS_YEARS_LDS=20480
-run b64 HDP_METRICS_BATCH=65536
-run b48 HDP_METRICS_BATCH=49152
-run b128 HDP_METRICS_BATCH=131072
+run w15 HDP_DBG_LIB=hdp_amd/libhdp_w15.so
+run w16 HDP_DBG_LIB=hdp_amd/libhdp_w16.so
+run w15lds20 HDP_DBG_LIB=hdp_amd/libhdp_w15.so HDP_METRICS_YEARS_LDS=20480
+run w16lds20 HDP_DBG_LIB=hdp_amd/libhdp_w16.so HDP_METRICS_YEARS_LDS=20480
