@@ -261,3 +261,32 @@ def test_irregular_calendars_keep_the_day_aligned_words():
     north, south, _ = cal.hemisphere_season_tables(dates)
     plan = core.MetricsPlan(doy_map, 365, [[3, 0, 0]], north, south, 2)
     assert "exceed_years_kernel" not in plan.describe()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_regular_calendars_definitions_and_record_lengths(seed, monkeypatch):
+    """Randomised sweep of the round-2 metrics path: calendar length in (320, 384], record length (whole and partial years, short
+    and beyond 24 years), 1..12 percentiles, 1..8 definitions with a random share of max_break = 0 (simple pairs, odd counts,
+    two passes), both hemispheres inside every wave -- year-aligned path against the oracle and the day-aligned path."""
+    rng = np.random.default_rng(9000 + seed)
+    n_doy = int(rng.choice([365, 365, 365, 360, 366, int(rng.integers(321, 385))]))
+    years = int(rng.choice([2, 5, 9, 26, 33]))
+    T = years * n_doy + int(rng.choice([0, 0, 1, 63, 64, 200, n_doy - 1]))
+    if T > 65535:
+        T = 65535
+    P = int(rng.integers(1, 13))
+    D = int(rng.integers(1, 9))
+    defs = [[int(rng.integers(0, 8)), 0 if rng.random() < 0.5 else int(rng.integers(1, 4)), int(rng.integers(0, 3))]
+            for _ in range(D)]
+    monkeypatch.setenv("HDP_METRICS_YEARS", "2")
+    case = _regular_case(9100 + seed, n_doy, T, 67, P, defs, long_runs=bool(seed & 1))
+    x, thr, doy_map, dfs, north, south, is_south = case
+    if north.shape[0] == 0:
+        pytest.skip("no complete season in this record")
+    want = c_oracle.metrics(x, thr, doy_map, dfs, north, south, is_south)
+    got = core.compute_heatwave_metrics(*case)
+    assert np.array_equal(got.astype(np.int64), want), (n_doy, T, P, defs)
+    monkeypatch.setenv("HDP_METRICS_YEARS", "0")
+    monkeypatch.setenv("HDP_METRICS_SIMPLE", "0")
+    assert np.array_equal(core.compute_heatwave_metrics(*case), got), (n_doy, T, P, defs)
