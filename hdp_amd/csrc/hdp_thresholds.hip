@@ -2256,7 +2256,10 @@ int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, 
   const int64_t T = plan->T;
   const int64_t chunk = std::min<int64_t>(n_cells, std::max<int64_t>(256, (int64_t(5) << 30) / (T * 4)));
   if (!plan->tm_stream) {
-    HDP_HIP_TRY(hipStreamCreateWithFlags(&plan->tm_stream, hipStreamNonBlocking));
+    // the copy stream gets the highest priority: its workgroups are dispatched ahead of the next chunk's kernel
+    int prio_lo = 0, prio_hi = 0;
+    HDP_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HDP_HIP_TRY(hipStreamCreateWithPriority(&plan->tm_stream, hipStreamNonBlocking, prio_hi));
     HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_fork, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
       HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_copied[i], hipEventDisableTiming));
