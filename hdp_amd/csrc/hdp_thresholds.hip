@@ -825,6 +825,11 @@ __device__ __forceinline__ void emit_targets_lanes(const ThrDev &pd, const TgtLa
   next_rank = rank_k;
 }
 
+// 32-bit read at an absolute LDS byte address
+__device__ __forceinline__ uint32_t lds_u32(uint32_t addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(uintptr_t(addr));
+}
+
 template <bool TOP, int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
                                                const float *tail_cur, const uint16_t *cl, int r, const RowFlags &rf,
@@ -846,6 +851,9 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
     // 4 * NG entries with the pseudo column (all sentinels), so this is branch-free: two 16-byte reads of the list,
     // every head read in flight at once.
     uint32_t pos[4 * NG];
+    // absolute LDS byte address of the image (the low 32 bits of a generic pointer into LDS): heads carry absolute
+    // addresses, so a step's next-key read needs no base add
+    const uint32_t img0 = uint32_t(reinterpret_cast<uintptr_t>(image));
     {
       const uint4 *cl4 = reinterpret_cast<const uint4 *>(cl);
 #pragma unroll
@@ -861,14 +869,14 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int j0 = v4 * 8 + 2 * u;
-          if (j0 < 4 * NG) pos[j0] = uint32_t(int(wv[u] & 0xffffu) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
-          if (j0 + 1 < 4 * NG) pos[j0 + 1] = uint32_t(int(wv[u] >> 16) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
+          if (j0 < 4 * NG) pos[j0] = img0 + uint32_t(int(wv[u] & 0xffffu) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
+          if (j0 + 1 < 4 * NG) pos[j0 + 1] = img0 + uint32_t(int(wv[u] >> 16) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
         }
       }
     }
     uint32_t kb[4 * NG];
 #pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) kb[j] = *reinterpret_cast<const uint32_t *>(image + pos[j]);
+    for (int j = 0; j < 4 * NG; ++j) kb[j] = lds_u32(pos[j]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       double hd[4];
@@ -893,7 +901,7 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
   auto issue = [&](double top) {
     lo_cur = uint32_t(__double2loint(top));
     g_cur = lo_cur & 3u;
-    nk = *reinterpret_cast<const uint32_t *>(image + (lo_cur & 0x3fffcu) + (TOP ? 4 : -4));
+    nk = lds_u32((lo_cur & 0x3fffcu) + (TOP ? 4u : uint32_t(-4)));  // payloads hold absolute LDS addresses
     h12 = *reinterpret_cast<const double2 *>(sA + g_cur * (ROWS * 16));
     h3 = *reinterpret_cast<const double *>(sB + g_cur * (ROWS * 8));
   };
