@@ -257,7 +257,9 @@ def main():
     traffic = None
     try:
         tp = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_cell.json")))
-        if tp.get("workload") == args.config and tp[dom].get("kernel", "") in kern[dom]["kernel"]:
+        if tp.get("workload") != args.config:
+            tp = tp.get("workloads", {}).get(args.config, {})
+        if tp and tp[dom].get("kernel", "") in kern[dom]["kernel"]:
             traffic = float(tp[dom]["bytes_per_cell"]) * nb0
     except Exception:
         traffic = None
