@@ -79,13 +79,18 @@ def main():
                     help="rehearsal: every rank uses GPU 0 (needs --backend gloo and a small --cells)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: no launcher set the rank environment, so this process becomes the launcher --
+        # BEFORE torch or the HIP library is touched here -- and only relays its ranks' output and worst exit code
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.share_device:
         local_rank = 0
@@ -394,7 +399,7 @@ def main():
     # It runs after the timed region and must never cost the bench line: an exception is reported in the line, and a
     # collective that does not come back within --allgather-timeout seconds (a second RCCL communicator next to torch's
     # has only been rehearsed with one rank on the one-GPU box) is abandoned -- rank 0 prints the line without it and every
-    # rank leaves through os._exit.
+    # rank leaves through os._exit(3): non-zero, so a launcher never takes a hung collective for a success.
     allgather = None
     if world > 1:
         import threading
@@ -406,7 +411,7 @@ def main():
             if rank == 0:
                 emit({"error": f"all-gather did not finish within {args.allgather_timeout:.0f} s; abandoned"})
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)     # an abandoned collective is a failure of the run: the launcher must see it
 
         timer = threading.Timer(args.allgather_timeout, bail)
         timer.daemon = True
@@ -425,6 +430,37 @@ def main():
         if hdist.comm_world() > 1 or hdist.comm_ready():
             hdist.comm_destroy()
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """Start `n` fresh rank processes of this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as a
+    launcher would) and wait for them.  Rank 0 inherits stdout, so its JSON line is this command's line; the return
+    value is the worst exit code of the ranks (a rank killed by a signal counts as 128 + signal)."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1" if r else str(os.cpu_count() or 1))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        for pr in procs:
+            rc = pr.wait()
+            rc = 128 - rc if rc < 0 else rc
+            worst = max(worst, rc)
+    except KeyboardInterrupt:
+        for pr in procs:
+            pr.terminate()
+        worst = max(worst, 130)
+    return worst
 
 
 def bench_time_major(lib, torch, dev, stream, tplan, mplan, xb, xm, thr, out, south, nb, M, T, n_doy, P, ms_thr, ms_met):
@@ -479,6 +515,23 @@ def bench_allgather(lib, torch, dist, hdist, dev, stream, args, out, world, rank
     share = int(min(share, free_b * 0.8 / 2 / world)) & ~3
     if args.backend != "nccl":
         share = min(share, 1 << 24)
+    # every rank must hand the SAME count to the collective: shards differ when the grid does not divide by the world
+    # and free memory differs per GPU, and unequal counts are undefined for ncclAllGather / ncclSend / ncclRecv
+    agreed = torch.tensor([share], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+    share = int(agreed.item()) & ~3
+    if share <= 0:
+        return {"skipped": "a rank has no metrics to gather"}
+    # one checksum per rank of the bytes it contributes, gathered through torch's group: every slice of the gathered
+    # buffer is compared with its owner's checksum, not only this rank's own
+    mine = out[:share].view(torch.int32).sum(dtype=torch.int64).reshape(1)      # no widened temporary
+    sums = torch.empty(world, dtype=torch.int64, device=mine.device)
+    if args.backend == "nccl":
+        dist.all_gather_into_tensor(sums, mine)
+    else:
+        sums_c = torch.empty(world, dtype=torch.int64)
+        dist.all_gather_into_tensor(sums_c, mine.cpu())
+        sums = sums_c
         gathered = torch.empty(share * world, dtype=torch.int16)
         g8, o8 = gathered.view(torch.uint8), out[:share].cpu().view(torch.uint8)
         dist.all_gather_into_tensor(g8, o8)
@@ -489,7 +542,9 @@ def bench_allgather(lib, torch, dist, hdist, dev, stream, args, out, world, rank
             dist.all_gather_into_tensor(g8, o8)
         fence()
         dt = (time.perf_counter() - t1) / reps
-        return {"path": "gloo rehearsal (host bytes)", "bytes_per_rank": share * 2, "ms": dt * 1e3}
+        ok = bool(torch.equal(gathered.view(world, share).view(torch.int32).sum(dim=1, dtype=torch.int64), sums))
+        return {"path": "gloo rehearsal (host bytes)", "bytes_per_rank": share * 2, "ms": dt * 1e3,
+                "every_shard_intact": ok}
     # RCCL behind the C ABI: rank 0 makes the unique id, torch.distributed carries its 128 bytes to the other ranks
     ident = torch.zeros(hdist.COMM_ID_BYTES, dtype=torch.uint8)
     if rank == 0:
@@ -509,7 +564,9 @@ def bench_allgather(lib, torch, dist, hdist, dev, stream, args, out, world, rank
         fence()
         dt = (time.perf_counter() - t1) / reps
         ok = bool(torch.equal(gathered[rank * share:(rank + 1) * share], out[:share]))
-        res[name] = {"ms": dt * 1e3, "recv_GBps_per_gpu": share * 2 * (world - 1) / dt / 1e9, "own_shard_intact": ok}
+        ok_all = bool(torch.equal(gathered.view(world, share).view(torch.int32).sum(dim=1, dtype=torch.int64), sums))
+        res[name] = {"ms": dt * 1e3, "recv_GBps_per_gpu": share * 2 * (world - 1) / dt / 1e9, "own_shard_intact": ok,
+                     "every_shard_intact": ok_all}
     res["ms"] = res["allgather"]["ms"]
     return res
 

@@ -59,6 +59,9 @@ SIGNATURES = {
     "hdp_metrics_f32_dev": (C.c_int, [vp, vp, vp, i64, vp, i64, vp, vp]),
     "hdp_metrics_f32": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, vp]),
     "hdp_metrics_f32_planes_i64": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, vp]),
+    "hdp_metrics_f32_layout_i16": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, vp]),
+    "hdp_metrics_f32_planes_i64_sharded": (C.c_int, [vp, i64, i64, i64, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp,
+                                                     i64, i64, vp, P(i64)]),
     "hdp_index_heatwaves": (C.c_int, [vp, i64, i64, i64, i64, i64, vp]),
     "hdp_season_metrics": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
     "hdp_indicate_hot_days": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
@@ -85,12 +88,51 @@ _lock = threading.Lock()
 _initialised_device = None
 
 
+def _share_hip_runtime():
+    """One HIP runtime per process, whatever the import order.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under the same sonames as the system ROCm.  If
+    libhdp_hip.so is loaded first it pulls in the system copies, and a later ``import torch`` then mixes them with its
+    bundled ones and reports "No HIP GPUs are available"; loaded after torch, libhdp_hip.so simply binds to the copies
+    torch already mapped, and both sides share one runtime.  So when torch is installed but not imported yet, map
+    ITS copies first -- the state the torch-first order produces -- without importing torch.
+    ``HDP_HIP_RUNTIME=system`` skips this (the process must then never import torch after hdp_amd);
+    returns which runtime the library will bind to, for device_info() and error messages."""
+    import sys
+    if os.environ.get("HDP_HIP_RUNTIME", "").lower() == "system":
+        return "system"
+    if "torch" in sys.modules:
+        return "torch (already imported)"
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return "system"
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    mapped = []
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+                mapped.append(name)
+            except OSError:
+                return "system"
+    return f"torch's bundled copies ({', '.join(mapped)})" if mapped else "system"
+
+
+hip_runtime = None   # set by load(): which libamdhip64 the library is bound to
+
+
 def load():
     """dlopen the library and bind every declared symbol (no GPU needed)."""
-    global _lib
+    global _lib, hip_runtime
     with _lock:
         if _lib is not None:
             return _lib
+        hip_runtime = _share_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -101,6 +101,57 @@ def compute_heatwave_metrics(x, thresholds, doy_map, hw_definitions, north, sout
     return out
 
 
+def compute_heatwave_metrics_layout(x, thresholds, doy_map, hw_definitions, north, south, is_south):
+    """The same pass, returned in the DEVICE layout: int16 [4, P, D, Y, n_series], series-minor -- the form a collective
+    moves when the grid is sharded over ranks (hdp_amd.dist): 2 bytes per value, and shards of the last axis
+    concatenate row by row."""
+    lib = _lib.ensure_device()
+    x, sc, st = _as_series_2d(x)
+    thr = np.ascontiguousarray(thresholds, dtype=np.float64)
+    dm = np.ascontiguousarray(doy_map, dtype=np.int64)
+    defs = np.ascontiguousarray(np.asarray(hw_definitions, dtype=np.int64).reshape(-1, 3))
+    north = np.ascontiguousarray(north, dtype=np.int64).reshape(-1, 2)
+    south = np.ascontiguousarray(south, dtype=np.int64).reshape(-1, 2)
+    hemi = np.ascontiguousarray(is_south, dtype=np.uint8)
+    n, T = x.shape
+    n_thr, n_doy, P = thr.shape
+    D, Y = defs.shape[0], north.shape[0]
+    if dm.size != T or hemi.size != n or south.shape[0] != Y:
+        raise ValueError("inconsistent table sizes")
+    out = np.zeros((4, P, D, Y, n), dtype=np.int16)
+    if n:
+        _lib.check(lib.hdp_metrics_f32_layout_i16(_ptr(x), n, T, sc, st, _ptr(thr), n_thr, n_doy, P, _ptr(dm), _ptr(defs),
+                                                  D, _ptr(north), _ptr(south), _ptr(hemi), Y, _ptr(out)))
+    return out
+
+
+def compute_heatwave_metric_planes_sharded(x, thresholds, doy_map, hw_definitions, north, south, is_south, n_mem,
+                                           n_total):
+    """Collective over the library's RCCL communicator (hdp_amd.dist.comm_init_rank / init_from_env): this rank passes
+    ITS cells -- x [n_mem * n_loc, T] member-major, thresholds [n_loc, n_doy, P] -- of a grid of n_total cells; the int16
+    result is all-gathered on the device and widened once there.  -> (int64 [4, P, D, n_mem * n_total, Y], bytes this
+    rank handed to the collective); every rank receives the whole grid's planes."""
+    lib = _lib.ensure_device()
+    x, sc, st = _as_series_2d(x)
+    thr = np.ascontiguousarray(thresholds, dtype=np.float64)
+    dm = np.ascontiguousarray(doy_map, dtype=np.int64)
+    defs = np.ascontiguousarray(np.asarray(hw_definitions, dtype=np.int64).reshape(-1, 3))
+    north = np.ascontiguousarray(north, dtype=np.int64).reshape(-1, 2)
+    south = np.ascontiguousarray(south, dtype=np.int64).reshape(-1, 2)
+    hemi = np.ascontiguousarray(is_south, dtype=np.uint8)
+    n, T = x.shape
+    n_loc, n_doy, P = thr.shape
+    D, Y = defs.shape[0], north.shape[0]
+    if n != n_mem * n_loc or dm.size != T or hemi.size != n or south.shape[0] != Y:
+        raise ValueError("inconsistent table sizes")
+    out = np.zeros((4, P, D, int(n_mem) * int(n_total), Y), dtype=np.int64)
+    wire = C.c_int64(0)
+    _lib.check(lib.hdp_metrics_f32_planes_i64_sharded(_ptr(x), int(n_mem), n_loc, T, sc, st, _ptr(thr), n_doy, P, _ptr(dm),
+                                                      _ptr(defs), D, _ptr(north), _ptr(south), _ptr(hemi), Y,
+                                                      int(n_total), _ptr(out), C.byref(wire)))
+    return out, int(wire.value)
+
+
 def compute_heatwave_metric_planes(x, thresholds, doy_map, hw_definitions, north, south, is_south):
     """The same pass, returned as int64 [4, P, D, n_series, Y]: one contiguous plane per output variable
     (HWF, HWN, HWD, HWA) in the dims and dtype compute_individual_metrics hands to xarray (metric.py:418-431)."""

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -35,10 +36,11 @@ hipStream_t default_stream() { return g_stream; }
 // so a call from another host thread with LOCAL_RANK != 0 would otherwise allocate and launch on device 0).
 bool device_ready() {
   if (g_device < 0) return false;
-  static thread_local int bound = -1;
-  if (bound != g_device) {
+  // checked on EVERY call, not once per thread: the caller may have switched this thread to another device since
+  // (torch.cuda.set_device), and the library's allocations, streams and launches all belong to g_device
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != g_device) {
     if (hipSetDevice(g_device) != hipSuccess) return false;
-    bound = g_device;
   }
   return true;
 }
@@ -538,16 +540,22 @@ int hdp_metrics_f32_dev(const hdp_metrics_plan *plan, const float *x_dev, const 
   return launch_metrics(plan, x_dev, thr_dev, n_thr_cells, is_south_dev, n_cells, out_dev, pick(stream));
 }
 
-// Host-pointer metrics call; `planes` selects the result form:
-//   false  int16 [P][D][n_cells][4][Y]   the reference's gufunc block order (hdp_metrics_f32)
-//   true   int64 [4][P][D][n_cells][Y]   one plane per output variable (hdp_metrics_f32_planes_i64)
-static int metrics_host(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
-                        const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
-                        const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
-                        const int64_t *south, const uint8_t *is_south, int64_t Y, void *out, bool planes) {
+// Host-pointer metrics calls.  The series are uploaded and processed in bounded chunks; `sink` receives every chunk's
+// result in the device layout [4][P][D][Y][nc] (int16) and disposes of it (repack + download, widen + download,
+// deposit in a shard buffer ...).  The forms:
+//   hdp_metrics_f32                int16 [P][D][n_cells][4][Y]   the reference's gufunc block order
+//   hdp_metrics_f32_planes_i64     int64 [4][P][D][n_cells][Y]   one plane per output variable
+//   hdp_metrics_f32_layout_i16     int16 [4][P][D][Y][n_cells]   the device layout itself (what a collective moves)
+//   hdp_metrics_f32_planes_i64_sharded   the rank's cells -> int16 all-gather on the device -> int64 planes of the grid
+using MetricsSink = std::function<int(int64_t c0, int64_t nc, int64_t chunk, const int16_t *dout_dev)>;
+static int metrics_host_chunks(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
+                               const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                               const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
+                               const int64_t *south, const uint8_t *is_south, int64_t Y, size_t extra_bytes_per_cell,
+                               const MetricsSink &sink) {
   HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
   HDP_REQUIRE(n_cells >= 0 && n_thr_cells > 0, HDP_EINVAL, "bad cell counts");
-  HDP_REQUIRE(n_cells == 0 || (x && thr && is_south && (out || Y == 0)), HDP_EINVAL, "NULL buffer");
+  HDP_REQUIRE(n_cells == 0 || (x && thr && is_south), HDP_EINVAL, "NULL buffer");
   HDP_REQUIRE(n_cells % n_thr_cells == 0, HDP_EINVAL,
               "n_cells must be a multiple of the number of threshold cells");
   hdp_metrics_plan *plan = nullptr;
@@ -556,7 +564,7 @@ static int metrics_host(const float *x, int64_t n_cells, int64_t T, int64_t stri
   std::unique_ptr<hdp_metrics_plan> guard(plan);
   if (n_cells == 0 || Y == 0) return HDP_OK;
   // thresholds stay resident for the whole call; series are processed in chunks
-  DevBuf dthr, dx, dsouth, dout, dref;
+  DevBuf dthr, dx, dsouth, dout;
   {  // the reference's (cell, doy, percentile) -> device layout [cell][P][n_doy]
     DevBuf dthr_ref;
     HDP_HIP_TRY(dthr_ref.upload(thr, size_t(n_thr_cells) * n_doy * P * 8));
@@ -566,20 +574,16 @@ static int metrics_host(const float *x, int64_t n_cells, int64_t T, int64_t stri
     HDP_HIP_TRY(hipStreamSynchronize(g_stream));
   }
   // chunks are multiples of n_thr_cells when members share thresholds, so (c % n_thr_cells) holds
-  int64_t chunk = chunk_cells_for(n_cells, T * 4 + 4 * P * D * (Y + Y) * 2);
+  int64_t chunk = chunk_cells_for(n_cells, T * 4 + 4 * P * D * Y * 2 + extra_bytes_per_cell);
   if (n_thr_cells < n_cells) {
     chunk = std::max<int64_t>(n_thr_cells, chunk / n_thr_cells * n_thr_cells);
   }
   HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
   HDP_HIP_TRY(dsouth.alloc(size_t(chunk)));
-  const size_t esz = planes ? 8 : 2;  // bytes per value of the result
   HDP_HIP_TRY(dout.alloc(size_t(4) * P * D * chunk * Y * 2));
-  HDP_HIP_TRY(dref.alloc(size_t(4) * P * D * chunk * Y * esz));
   SeriesUploader up;
   rc = up.prepare(x, n_cells, T, stride_cell, stride_time, whole_matrix_limit(), g_stream);
   if (rc != HDP_OK) return rc;
-  ResultPrefault pre;
-  pre.start(out, size_t(P) * D * n_cells * 4 * Y * esz);  // the whole result, ahead of the first download
   for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
     const int64_t nc = std::min(chunk, n_cells - c0);
     rc = up.upload(x, c0, nc, T, stride_cell, stride_time, dx.as<float>(), g_stream);
@@ -591,8 +595,39 @@ static int metrics_host(const float *x, int64_t n_cells, int64_t T, int64_t stri
     rc = launch_metrics(plan, dx.as<float>(), thr_base, ntc, dsouth.as<uint8_t>(), nc, dout.as<int16_t>(),
                         g_stream);
     if (rc != HDP_OK) return rc;
-    rc = planes ? launch_metrics_planes_i64(dout.as<int16_t>(), P, D, nc, Y, dref.as<int64_t>(), g_stream)
-                : launch_metrics_repack(dout.as<int16_t>(), P, D, nc, Y, dref.as<int16_t>(), g_stream);
+    rc = sink(c0, nc, chunk, dout.as<int16_t>());
+    if (rc != HDP_OK) return rc;
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  }
+  return HDP_OK;
+}
+
+enum MetForm { MET_REPACK16 = 0, MET_PLANES64 = 1, MET_LAYOUT16 = 2 };
+
+static int metrics_host(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
+                        const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                        const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
+                        const int64_t *south, const uint8_t *is_south, int64_t Y, void *out, MetForm form) {
+  HDP_REQUIRE(n_cells <= 0 || Y == 0 || out, HDP_EINVAL, "NULL buffer");
+  const size_t esz = form == MET_PLANES64 ? 8 : 2;  // bytes per value of the result
+  DevBuf dref;
+  ResultPrefault pre;
+  bool started = false;
+  auto sink = [&](int64_t c0, int64_t nc, int64_t chunk, const int16_t *dout) -> int {
+    if (!started) {
+      started = true;
+      if (form != MET_LAYOUT16) HDP_HIP_TRY(dref.alloc(size_t(4) * P * D * chunk * Y * esz));
+      pre.start(out, size_t(P) * D * n_cells * 4 * Y * esz);  // the whole result, ahead of the first download
+    }
+    if (form == MET_LAYOUT16) {  // [4PD * Y] rows of nc values into rows of n_cells values
+      pre.wait();
+      HDP_HIP_TRY(hipMemcpy2DAsync(static_cast<char *>(out) + size_t(c0) * 2, size_t(n_cells) * 2, dout, size_t(nc) * 2,
+                                   size_t(nc) * 2, size_t(4) * P * D * Y, hipMemcpyDeviceToHost, g_stream));
+      return HDP_OK;
+    }
+    const bool planes = form == MET_PLANES64;
+    int rc = planes ? launch_metrics_planes_i64(dout, P, D, nc, Y, dref.as<int64_t>(), g_stream)
+                    : launch_metrics_repack(dout, P, D, nc, Y, dref.as<int16_t>(), g_stream);
     if (rc != HDP_OK) return rc;
     // the chunk's rows go straight to their places in the result: [P*D] rows of [nc][4][Y] into
     // [P*D][n_cells][4][Y], or [4*P*D] rows of [nc][Y] into [4*P*D][n_cells][Y]
@@ -602,9 +637,10 @@ static int metrics_host(const float *x, int64_t n_cells, int64_t T, int64_t stri
     HDP_HIP_TRY(hipMemcpy2DAsync(static_cast<char *>(out) + size_t(c0) * row_vals * esz, size_t(n_cells) * row_vals * esz,
                                  dref.p, size_t(nc) * row_vals * esz, size_t(nc) * row_vals * esz, n_rows,
                                  hipMemcpyDeviceToHost, g_stream));
-    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
-  }
-  return HDP_OK;
+    return HDP_OK;
+  };
+  return metrics_host_chunks(x, n_cells, T, stride_cell, stride_time, thr, n_thr_cells, n_doy, P, doy_map, defs, D, north,
+                             south, is_south, Y, form == MET_LAYOUT16 ? 0 : size_t(4) * P * D * Y * esz, sink);
 }
 
 int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
@@ -612,7 +648,7 @@ int hdp_metrics_f32(const float *x, int64_t n_cells, int64_t T, int64_t stride_c
                     const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
                     const int64_t *south, const uint8_t *is_south, int64_t Y, int16_t *out) {
   return metrics_host(x, n_cells, T, stride_cell, stride_time, thr, n_thr_cells, n_doy, P, doy_map, defs, D, north,
-                      south, is_south, Y, out, false);
+                      south, is_south, Y, out, MET_REPACK16);
 }
 
 int hdp_metrics_f32_planes_i64(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
@@ -620,7 +656,110 @@ int hdp_metrics_f32_planes_i64(const float *x, int64_t n_cells, int64_t T, int64
                                const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
                                const int64_t *south, const uint8_t *is_south, int64_t Y, int64_t *out) {
   return metrics_host(x, n_cells, T, stride_cell, stride_time, thr, n_thr_cells, n_doy, P, doy_map, defs, D, north,
-                      south, is_south, Y, out, true);
+                      south, is_south, Y, out, MET_PLANES64);
+}
+
+int hdp_metrics_f32_layout_i16(const float *x, int64_t n_cells, int64_t T, int64_t stride_cell, int64_t stride_time,
+                               const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                               const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
+                               const int64_t *south, const uint8_t *is_south, int64_t Y, int16_t *out) {
+  return metrics_host(x, n_cells, T, stride_cell, stride_time, thr, n_thr_cells, n_doy, P, doy_map, defs, D, north,
+                      south, is_south, Y, out, MET_LAYOUT16);
+}
+
+static ncclComm_t g_comm = nullptr;
+static int g_comm_rank = -1, g_comm_world = 0;
+
+// Sharded form of hdp_metrics_f32_planes_i64 (the reference's split is the dask graph of metric.py:444-452):
+// this rank holds the `n_loc` cells [rank * shard, rank * shard + n_loc) of a grid of `n_total` cells, shard =
+// ceil(n_total / world), as `n_mem` members x n_loc series (member-major) with the cells' own thresholds.  The int16
+// result stays on the device in the layout [4][P][D][Y][n_mem * shard] (zero columns where the rank owns fewer cells), is
+// all-gathered there by the library's communicator (2 bytes per value on the wire; the int64 planes would be four
+// times that), and is widened and regrouped ONCE, on the gathered buffer, into the int64 planes of the whole grid,
+// [4][P][D][n_mem * n_total][Y], which are downloaded into `out` in slabs.  *wire_bytes (optional) receives the bytes
+// this rank handed to the collective.
+int hdp_metrics_f32_planes_i64_sharded(const float *x, int64_t n_mem, int64_t n_loc, int64_t T, int64_t stride_cell,
+                                       int64_t stride_time, const double *thr, int64_t n_doy, int64_t P,
+                                       const int64_t *doy_map, const int64_t *defs, int64_t D, const int64_t *north,
+                                       const int64_t *south, const uint8_t *is_south, int64_t Y, int64_t n_total,
+                                       int64_t *out, int64_t *wire_bytes) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(g_comm, HDP_EINVAL, "no communicator (hdp_comm_init_rank)");
+  HDP_REQUIRE(n_mem >= 1 && n_loc >= 0 && n_total >= 0 && P >= 1 && D >= 1 && Y >= 0, HDP_EINVAL, "bad sizes");
+  const int64_t world = g_comm_world, rank = g_comm_rank;
+  const int64_t shard = (n_total + world - 1) / world;
+  const int64_t lo = std::min(n_total, rank * shard), hi = std::min(n_total, (rank + 1) * shard);
+  HDP_REQUIRE(n_loc == hi - lo, HDP_EINVAL, "rank %d of %d owns %lld cells of a grid of %lld, not %lld", (int)rank,
+              (int)world, (long long)(hi - lo), (long long)n_total, (long long)n_loc);
+  if (wire_bytes) *wire_bytes = 0;
+  if (n_total == 0 || Y == 0) return HDP_OK;
+  HDP_REQUIRE(out, HDP_EINVAL, "NULL output");
+  const int64_t rows = 4 * P * D * Y;          // rows of the device layout
+  const int64_t pad = n_mem * shard;           // series columns per rank, equal on every rank
+  const size_t shard_bytes = size_t(rows) * pad * 2;
+  DevBuf dlocal, dgath;
+  HDP_HIP_TRY(dlocal.alloc(shard_bytes));
+  HDP_HIP_TRY(dgath.alloc(shard_bytes * world));
+  HDP_HIP_TRY(hipMemsetAsync(dlocal.p, 0, shard_bytes, g_stream));
+  auto sink = [&](int64_t c0, int64_t nc, int64_t /*chunk*/, const int16_t *dout) -> int {
+    // series s = m * n_loc + c of the call -> column m * shard + c of the shard buffer: one 2-D copy per member touched
+    for (int64_t s0 = c0; s0 < c0 + nc;) {
+      const int64_t m = s0 / n_loc, c = s0 % n_loc;
+      const int64_t n = std::min(n_loc - c, c0 + nc - s0);
+      HDP_HIP_TRY(hipMemcpy2DAsync(dlocal.as<int16_t>() + m * shard + c, size_t(pad) * 2, dout + (s0 - c0), size_t(nc) * 2,
+                                   size_t(n) * 2, size_t(rows), hipMemcpyDeviceToDevice, g_stream));
+      s0 += n;
+    }
+    return HDP_OK;
+  };
+  // A rank whose local pass fails still enters the collectives (with whatever its shard buffer holds) and reports its
+  // code through a second, 4-byte all-gather: every rank then returns an error instead of one rank leaving the others
+  // blocked in ncclAllGather.
+  int local_rc = HDP_OK;
+  std::string local_msg;
+  if (n_loc > 0) {
+    local_rc = metrics_host_chunks(x, n_mem * n_loc, T, stride_cell, stride_time, thr, n_loc, n_doy, P, doy_map, defs,
+                                   D, north, south, is_south, Y, 0, sink);
+    if (local_rc != HDP_OK) local_msg = hdp_last_error();
+  }
+  DevBuf dstat;
+  HDP_HIP_TRY(dstat.alloc(size_t(4) * (world + 1)));
+  {
+    const int32_t mine = local_rc;
+    HDP_HIP_TRY(hipMemcpyAsync(dstat.as<int32_t>() + world, &mine, 4, hipMemcpyHostToDevice, g_stream));
+    ncclResult_t r = ncclAllGather(dlocal.p, dgath.p, shard_bytes, ncclInt8, g_comm, g_stream);
+    if (r == ncclSuccess) r = ncclAllGather(dstat.as<int32_t>() + world, dstat.p, 4, ncclInt8, g_comm, g_stream);
+    if (r != ncclSuccess) return set_error(HDP_EHIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
+    if (wire_bytes) *wire_bytes = (int64_t)shard_bytes;
+    std::vector<int32_t> stat(world);
+    HDP_HIP_TRY(hipMemcpyAsync(stat.data(), dstat.p, size_t(4) * world, hipMemcpyDeviceToHost, g_stream));
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+    if (local_rc != HDP_OK) return set_error(local_rc, "%s", local_msg.c_str());
+    for (int64_t r2 = 0; r2 < world; ++r2)
+      if (stat[r2] != HDP_OK)
+        return set_error(HDP_EHIP, "the local metrics pass failed on rank %d (code %d)", (int)r2, (int)stat[r2]);
+  }
+  dlocal.release();
+  // widen + regroup on the gathered buffer, slab by slab of (metric, percentile, definition) planes
+  const int64_t series = n_mem * n_total;
+  const int64_t mpd = 4 * P * D;
+  int64_t slab = std::max<int64_t>(1, (int64_t(1) << 30) / std::max<int64_t>(1, series * Y * 8));
+  slab = std::min(slab, mpd);
+  DevBuf dpl;
+  HDP_HIP_TRY(dpl.alloc(size_t(slab) * series * Y * 8));
+  ResultPrefault pre;
+  pre.start(out, size_t(mpd) * series * Y * 8);
+  for (int64_t r0 = 0; r0 < mpd; r0 += slab) {
+    const int64_t nr = std::min(slab, mpd - r0);
+    const int rc = launch_metrics_planes_i64_gathered(dgath.as<int16_t>(), mpd, Y, world, shard, n_mem, n_total, r0, nr,
+                                                      dpl.as<int64_t>(), g_stream);
+    if (rc != HDP_OK) return rc;
+    pre.wait();
+    HDP_HIP_TRY(hipMemcpyAsync(out + size_t(r0) * series * Y, dpl.p, size_t(nr) * series * Y * 8, hipMemcpyDeviceToHost,
+                               g_stream));
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  }
+  return HDP_OK;
 }
 
 const char *hdp_metrics_plan_describe(const hdp_metrics_plan *plan) {
@@ -668,9 +807,6 @@ int hdp_metrics_f32_tm_dev(const hdp_metrics_plan *plan, const float *x_tm_dev, 
 // north_star: "grid cells shard embarrassingly across the 8 GPUs of one node with an RCCL all-gather over xGMI only to
 // reassemble the final metrics Dataset".  The reference has no collective of its own (its data movement is implicit in
 // the dask graph: xarray.map_blocks threshold.py:161, metric.py:444; concat/merge threshold.py:229, metric.py:520).
-
-static ncclComm_t g_comm = nullptr;
-static int g_comm_rank = -1, g_comm_world = 0;
 
 int hdp_comm_unique_id(void *id_out) {
   static_assert(sizeof(ncclUniqueId) == HDP_COMM_ID_BYTES, "ncclUniqueId size");

@@ -226,6 +226,10 @@ int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64
 int launch_metrics_planes_i64(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,
                               int64_t *planes, hipStream_t stream);
 
+int launch_metrics_planes_i64_gathered(const int16_t *gathered, int64_t MPD, int64_t Y, int64_t world, int64_t shard,
+                                       int64_t n_mem, int64_t n_total, int64_t r0, int64_t nr, int64_t *planes,
+                                       hipStream_t stream);
+
 // numba rank arithmetic for one quantile over n samples; returns HDP_EQUANT for q
 // outside [0,1] (or NaN).  k_lo/k_hi are 0-based ASCENDING order-statistic indices.
 int quantile_param(double q, int64_t n, QuantileParam *qp, int64_t *k_lo, int64_t *k_hi);

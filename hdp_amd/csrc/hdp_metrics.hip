@@ -1314,6 +1314,25 @@ __global__ void metrics_planes_i64_kernel(const int16_t *__restrict__ src, int64
   }
 }
 
+// The same widening on the all-gathered shards of a grid (hdp_metrics_f32_planes_i64_sharded): src is
+// [world][MPD][Y][n_mem * shard] int16 -- rank r's columns m * shard + c are member m of grid cells r * shard + c --
+// dst the planes [nr][n_mem * n_total][Y] int64 of rows [r0, r0 + nr), series = member * n_total + grid cell.
+__global__ void metrics_planes_i64_gathered_kernel(const int16_t *__restrict__ src, int64_t MPD, int64_t Y, int64_t shard,
+                                                   int64_t n_mem, int64_t n_total, int64_t r0, int64_t nr,
+                                                   long long *__restrict__ dst) {
+  const int64_t series = n_mem * n_total, pad = n_mem * shard;
+  const int64_t total = nr * series * Y;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total;
+       i += int64_t(gridDim.x) * blockDim.x) {
+    const int64_t y = i % Y;
+    const int64_t s = (i / Y) % series;
+    const int64_t rr = i / (Y * series);
+    const int64_t m = s / n_total, g = s % n_total;
+    const int64_t r = g / shard, c = g % shard;
+    dst[i] = (long long)src[((r * MPD + r0 + rr) * Y + y) * pad + m * shard + c];
+  }
+}
+
 // ---- unit-level mirrors of the njit helpers --------------------------------------------------
 
 // metric.py:280-301
@@ -2130,6 +2149,18 @@ int launch_season_metrics(const int64_t *ids_dev, int64_t n_series, int64_t T, c
   if (n_series * Y == 0) return HDP_OK;
   hipLaunchKernelGGL(season_metrics_kernel, dim3((unsigned)((n_series * Y + 63) / 64)), dim3(64), 0, stream,
                      ids_dev, n_series, T, ranges_dev, Y, out_dev, hwa_dev);
+  HDP_HIP_TRY(hipGetLastError());
+  return HDP_OK;
+}
+
+int launch_metrics_planes_i64_gathered(const int16_t *gathered, int64_t MPD, int64_t Y, int64_t world, int64_t shard,
+                                       int64_t n_mem, int64_t n_total, int64_t r0, int64_t nr, int64_t *planes,
+                                       hipStream_t stream) {
+  (void)world;
+  const int64_t total = nr * n_mem * n_total * Y;
+  if (total == 0) return HDP_OK;
+  hipLaunchKernelGGL(metrics_planes_i64_gathered_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, gathered, MPD, Y,
+                     shard, n_mem, n_total, r0, nr, reinterpret_cast<long long *>(planes));
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
 }

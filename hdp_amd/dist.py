@@ -126,12 +126,22 @@ def init_from_env(port_offset: int = 29, timeout: float = 120.0):
     return rank, world
 
 
+# bytes this rank handed to the transport in its most recent gather (tests assert the int16 volume on the wire)
+last_wire_bytes = 0
+
+
+def _note_wire(nbytes: int) -> None:
+    global last_wire_bytes
+    last_wire_bytes = int(nbytes)
+
+
 def _allgather_bytes_rccl(local: np.ndarray) -> np.ndarray:
     """local: C-contiguous array, equal size on every rank -> [world, *local.shape] through hdp_allgather_dev."""
     lib = _lib.ensure_device()
     world = comm_world()
     nbytes = local.nbytes
     out = np.empty((world,) + local.shape, dtype=local.dtype)
+    _note_wire(nbytes)
     if nbytes == 0:
         return out
     send, recv = lib.hdp_dev_alloc(nbytes), lib.hdp_dev_alloc(nbytes * world)
@@ -147,21 +157,49 @@ def _allgather_bytes_rccl(local: np.ndarray) -> np.ndarray:
     return out
 
 
+def _torch_group():
+    try:
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            return tdist
+    except ImportError:
+        pass
+    return None
+
+
 def current(shard=None):
     """(rank, world) of this process: an explicit ``shard=(rank, world)``, else the library communicator, else an
     initialised torch.distributed group, else (0, 1)."""
     if shard is not None and shard != "auto":
         rank, world = shard
         return int(rank), int(world)
+    return transport()
+
+
+def transport():
+    """(rank, world) of the transport a gather would use: the library communicator, else torch's group, else (0, 1)."""
     if comm_ready():
         return comm_rank(), comm_world()
-    try:
-        import torch.distributed as tdist
-        if tdist.is_available() and tdist.is_initialized():
-            return tdist.get_rank(), tdist.get_world_size()
-    except ImportError:
-        pass
+    tdist = _torch_group()
+    if tdist is not None:
+        return tdist.get_rank(), tdist.get_world_size()
     return 0, 1
+
+
+def check_shard(shard):
+    """(rank, world) for a ``shard=`` argument, checked against the transport that will carry the gather: shard sizes and
+    padding come from the caller's (rank, world), the collective from the communicator -- if the two disagree the result
+    would be silently mis-shaped, so that is an error here."""
+    rank, world = current(shard)
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad shard {shard!r}")
+    if world > 1:
+        t_rank, t_world = transport()
+        if (t_rank, t_world) != (rank, world):
+            raise ValueError(f"shard=({rank}, {world}) but the initialised transport is rank {t_rank} of {t_world}: "
+                             "initialise hdp_amd.dist (comm_init_rank / init_from_env) or torch.distributed with the "
+                             "same ranks before calling a sharded adapter")
+    return rank, world
 
 
 def allgather_cells(local, n_cells: int, axis: int, group=None, device=None, world=None):
@@ -189,18 +227,105 @@ def allgather_cells(local, n_cells: int, axis: int, group=None, device=None, wor
     t = t.movedim(axis, 0).contiguous()
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     # bytes on the wire: neither RCCL nor gloo has an int16 datatype
+    _note_wire(t.numel() * t.element_size())
     dist.all_gather_into_tensor(out.view(torch.uint8).reshape(-1), t.view(torch.uint8).reshape(-1), group=group)
     out = out[:n_cells].movedim(0, axis)
     return out.cpu().numpy() if is_np else out
 
 
-def sharded_over_cells(fn, n_cells: int, axis: int, shard):
+def agree(ok: bool, what: str = "") -> None:
+    """Collective: raise on EVERY rank if any rank reports a failure (one byte per rank through the transport), so a
+    rank whose local computation raised never leaves the others blocked in the data collective."""
+    _, world = transport()
+    if world == 1:
+        if not ok:
+            raise RuntimeError(what or "local computation failed")
+        return
+    flag = np.array([0 if ok else 1], dtype=np.uint8)
+    if comm_ready():
+        flags = _allgather_bytes_rccl(flag).reshape(-1)
+    else:
+        import torch
+        tdist = _torch_group()
+        out = torch.empty(world, dtype=torch.uint8)
+        tdist.all_gather_into_tensor(out, torch.from_numpy(flag))
+        flags = out.numpy()
+    bad = [int(r) for r in np.nonzero(flags)[0]]
+    if bad:
+        raise RuntimeError(f"sharded call failed on rank(s) {bad}" + (f": {what}" if what and not ok else ""))
+
+
+def sharded_over_cells(fn, n_cells: int, axis: int, shard, empty=None):
     """Run ``fn(lo, hi)`` on this rank's cell range and all-gather the results along ``axis`` (the output's cell
-    axis): what the ``shard=`` argument of the hdp_amd.threshold / hdp_amd.metric adapters does."""
-    rank, world = current(shard)
+    axis): what the ``shard=`` argument of the hdp_amd.threshold / hdp_amd.metric adapters does.
+
+    A rank that owns no cells (``shard_bounds`` gives trailing ranks an empty range when the grid is small) does not
+    call ``fn``: it contributes ``empty(0)`` -- an array with a zero-length cell axis (default: ``fn``'s result shape is
+    learned from the other ranks being unnecessary, the padding supplies it) -- and still takes part in the collectives.
+    Every rank then agrees on success BEFORE the data collective, so an exception on one rank is raised on all."""
+    rank, world = check_shard(shard)
     if world == 1:
         return fn(0, n_cells)
     lo, hi = shard_bounds(n_cells, world, rank)
-    local = fn(lo, hi)
-    local = pad_cells(np.asarray(local), shard_size(n_cells, world), axis)
+    local, err = None, None
+    try:
+        if hi > lo:
+            local = np.asarray(fn(lo, hi))
+        elif empty is not None:
+            local = np.asarray(empty(0))
+    except Exception as e:        # noqa: BLE001 -- re-raised below, on every rank
+        err = e
+    try:
+        agree(err is None, f"{type(err).__name__}: {err}" if err else "")
+    except RuntimeError:
+        if err is not None:
+            raise err
+        raise
+    # shape and dtype of a shard: from this rank's result, or -- where the rank owns nothing and no `empty` was
+    # given -- from a rank that does (rank 0 always owns cells when n_cells > 0)
+    meta = _share_meta(local, axis)
+    if local is None:
+        shape = list(meta[0])
+        shape[axis] = 0
+        local = np.zeros(shape, dtype=meta[1])
+    local = pad_cells(local, shard_size(n_cells, world), axis)
     return allgather_cells(local, n_cells, axis, world=world)
+
+
+def _share_meta(local, axis):
+    """(shape, dtype) of rank 0's local result, broadcast as a small fixed-size record (rank 0 owns cells whenever the
+    grid has any)."""
+    rec = np.zeros(16, dtype=np.int64)
+    if local is not None:
+        rec[0] = local.ndim
+        rec[1:1 + local.ndim] = local.shape
+        rec[15] = np.dtype(local.dtype).num
+    if comm_ready():
+        allr = _allgather_bytes_rccl(rec)
+    else:
+        import torch
+        tdist = _torch_group()
+        _, world = transport()
+        out = torch.empty(world * 16, dtype=torch.int64)
+        tdist.all_gather_into_tensor(out, torch.from_numpy(rec))
+        allr = out.numpy().reshape(world, 16)
+    r0 = allr[0]
+    nd = int(r0[0])
+    dt = [np.dtype(t) for t in (np.int16, np.int32, np.int64, np.float32, np.float64, np.uint8) if np.dtype(t).num == int(r0[15])]
+    return tuple(int(v) for v in r0[1:1 + nd]), (dt[0] if dt else np.dtype(np.float64))
+
+
+def gather_metric_planes(layout_local: np.ndarray, n_mem: int, n_cells: int, shard) -> np.ndarray:
+    """int16 device-layout result of this rank's cells, [4, P, D, Y, n_mem * n_loc] (series member-major), -> the int64
+    planes of the whole grid [4, P, D, n_mem, n_cells, Y] on every rank.  The collective moves the int16 values (2 bytes
+    each; widening first would put four times the bytes on the wire); widening and the (year, series) regrouping happen
+    once, on the gathered array.  Used with a torch.distributed group; with the library communicator the same happens
+    on the device (core.compute_heatwave_metric_planes_sharded)."""
+    rank, world = check_shard(shard)
+    lo, hi = shard_bounds(n_cells, world, rank)
+    n_loc = hi - lo
+    four, P, D, Y = layout_local.shape[:4]
+    loc = layout_local.reshape(four, P, D, Y, n_mem, n_loc)
+    loc = pad_cells(loc, shard_size(n_cells, world), 5)
+    full = allgather_cells(np.ascontiguousarray(loc), n_cells, 5, world=world)      # int16 [4, P, D, Y, n_mem, n_cells]
+    return np.ascontiguousarray(np.moveaxis(full, 3, 5)).astype(np.int64)          # [4, P, D, n_mem, n_cells, Y]

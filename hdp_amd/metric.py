@@ -109,21 +109,36 @@ def compute_individual_metrics(measure, threshold, hw_definitions, include_thres
 
     # int64 planes [metric][P][D][series][Y] (int, as test_workflow.py:57), widened and regrouped on the device
     D, Y = len(hw_definitions), north.shape[0]
-    if shard is None:
+    if shard is None or hdist.check_shard(shard)[1] == 1:
         planes = core.compute_heatwave_metric_planes(x2d, thr3, doy_map, hw_definitions, north, south, is_south)
     else:
+        # this rank's cells only (all members of a cell stay here, with the cell's thresholds); the collective moves
+        # the int16 device layout -- never the widened int64 planes -- and the result is widened once, after it
+        rank, world = hdist.check_shard(shard)
         n_thr = thr3.shape[0]
         n_mem = x2d.shape[0] // n_thr          # series are member-major: [member][cell]
-        x3 = x2d.reshape(n_mem, n_thr, -1)
-        south2 = is_south.reshape(n_mem, n_thr)
-
-        def local(lo, hi):   # -> [4, P, D, member, cells of this rank, Y]
-            pl = core.compute_heatwave_metric_planes(np.ascontiguousarray(x3[:, lo:hi]).reshape(n_mem * (hi - lo), -1),
-                                                     thr3[lo:hi], doy_map, hw_definitions, north, south,
-                                                     np.ascontiguousarray(south2[:, lo:hi]).reshape(-1))
-            return pl.reshape(4, P, D, n_mem, hi - lo, Y)
-
-        planes = hdist.sharded_over_cells(local, n_thr, 4, shard)
+        lo, hi = hdist.shard_bounds(n_thr, world, rank)
+        x_loc = np.ascontiguousarray(x2d.reshape(n_mem, n_thr, x2d.shape[-1])[:, lo:hi]).reshape(n_mem * (hi - lo), x2d.shape[-1])
+        south_loc = np.ascontiguousarray(is_south.reshape(n_mem, n_thr)[:, lo:hi]).reshape(-1)
+        if hdist.comm_ready():     # library communicator: gather and widen on the device (RCCL over xGMI)
+            planes, wire = core.compute_heatwave_metric_planes_sharded(x_loc, thr3[lo:hi], doy_map, hw_definitions, north,
+                                                                       south, south_loc, n_mem, n_thr)
+            hdist._note_wire(wire)
+        else:                      # torch.distributed group (gloo in the CPU tests): int16 through the group
+            err, lay = None, None
+            try:
+                lay = (core.compute_heatwave_metrics_layout(x_loc, thr3[lo:hi], doy_map, hw_definitions, north, south,
+                                                            south_loc)
+                       if hi > lo else np.zeros((4, P, D, Y, 0), dtype=np.int16))
+            except Exception as e:        # noqa: BLE001 -- raised on every rank by agree()
+                err = e
+            try:
+                hdist.agree(err is None, f"{type(err).__name__}: {err}" if err else "")
+            except RuntimeError:
+                if err is not None:
+                    raise err
+                raise
+            planes = hdist.gather_metric_planes(lay, n_mem, n_thr, shard)
     planes = planes.reshape((4, P, D) + tuple(proc_shape) + (Y,))
     # back to the measure's own dim order (a view; only the member dim ever moves)
     src = ["metric", "percentile", "definition"] + proc_dims + ["year"]

@@ -196,6 +196,32 @@ int hdp_metrics_f32_planes_i64(const float *x, int64_t n_cells, int64_t T,
                                const int64_t *north, const int64_t *south,
                                const uint8_t *is_south, int64_t Y, int64_t *out);
 
+/* Same call; out [4][P][D][Y][n_cells] int16: the device layout itself, series-minor -- what a collective moves when
+ * the cells of a grid are sharded over ranks (2 bytes per value; the shards of a cell axis that is last concatenate
+ * row by row). */
+int hdp_metrics_f32_layout_i16(const float *x, int64_t n_cells, int64_t T,
+                               int64_t stride_cell, int64_t stride_time,
+                               const double *thr, int64_t n_thr_cells, int64_t n_doy, int64_t P,
+                               const int64_t *doy_map, const int64_t *defs, int64_t D,
+                               const int64_t *north, const int64_t *south,
+                               const uint8_t *is_south, int64_t Y, int16_t *out);
+
+/* Sharded form of hdp_metrics_f32_planes_i64 (the reference's split over cells is the dask graph of
+ * metric.py:444-452).  Needs the library communicator (hdp_comm_init_rank, below).  This rank passes ITS cells of a
+ * grid of n_total cells -- the contiguous range [rank * shard, rank * shard + n_loc), shard = ceil(n_total / world) --
+ * as n_mem members x n_loc series (member-major; x [n_mem * n_loc][T]) with those cells' thresholds thr
+ * [n_loc][n_doy][P].  The int16 result stays on the device, is all-gathered there (ncclAllGather, 2 bytes per value
+ * on the wire) and is widened and regrouped once, on the gathered buffer: out [4][P][D][n_mem * n_total][Y] int64,
+ * series = member * n_total + grid cell, the complete result on every rank.  *wire_bytes (may be NULL): bytes this
+ * rank handed to the collective.  Collective: every rank of the communicator must call it (n_loc may be 0). */
+int hdp_metrics_f32_planes_i64_sharded(const float *x, int64_t n_mem, int64_t n_loc, int64_t T,
+                                       int64_t stride_cell, int64_t stride_time,
+                                       const double *thr, int64_t n_doy, int64_t P,
+                                       const int64_t *doy_map, const int64_t *defs, int64_t D,
+                                       const int64_t *north, const int64_t *south,
+                                       const uint8_t *is_south, int64_t Y, int64_t n_total,
+                                       int64_t *out, int64_t *wire_bytes);
+
 /* ---- unit-level mirrors of the njit helpers (for the known-answer tests) ---- */
 
 /* metric.py:11-60: hot [n_series][T] u8 -> ids [n_series][T] int64 */
