@@ -9,6 +9,7 @@
 #include <cmath>
 #include <functional>
 #include <future>
+#include <string>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -193,6 +194,58 @@ struct SeriesUploader {
   }
 };
 
+// Upload of the NEXT chunk of series under the kernels and the download of the current one (inputs
+// larger than HBM stream through the device in chunks / latitude bands).  A copy from pageable host memory blocks the
+// calling thread while the runtime stages it through its pinned buffers, so the upload runs on a helper thread with its
+// own stream into the other of two device buffers; the copy engine moves chunk k + 1 while the compute units work on
+// chunk k.  The helper's error text travels back with its code (hdp_last_error is per thread).
+struct AsyncUpload {
+  hipStream_t stream = nullptr;
+  std::future<int> pending;
+  std::string err;
+  ~AsyncUpload() {
+    if (pending.valid()) {
+      try { pending.get(); } catch (...) {}
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int init() {
+    HDP_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    return HDP_OK;
+  }
+  void start(SeriesUploader *up, const float *x, int64_t c0, int64_t nc, int64_t T, int64_t sc, int64_t st, float *dx) {
+    const int dev = g_device;
+    auto work = [this, up, x, c0, nc, T, sc, st, dx, dev]() -> int {
+      if (hipSetDevice(dev) != hipSuccess) {
+        err = "hipSetDevice failed on the upload thread";
+        return HDP_EHIP;
+      }
+      int rc = up->upload(x, c0, nc, T, sc, st, dx, stream);
+      if (rc == HDP_OK && hipStreamSynchronize(stream) != hipSuccess) rc = set_error(HDP_EHIP, "upload stream failed");
+      if (rc != HDP_OK) err = g_err;
+      return rc;
+    };
+    try {
+      pending = std::async(std::launch::async, work);
+    } catch (...) {  // no thread to be had: upload here, as before
+      std::promise<int> pr;
+      pr.set_value(work());
+      pending = pr.get_future();
+    }
+  }
+  int wait() {
+    if (!pending.valid()) return HDP_OK;
+    int rc = HDP_EHIP;
+    try {
+      rc = pending.get();
+    } catch (...) {
+      err = "the upload thread raised";
+    }
+    if (rc != HDP_OK) return set_error(rc, "%s", err.c_str());
+    return HDP_OK;
+  }
+};
+
 }  // namespace hdp
 
 using namespace hdp;
@@ -332,20 +385,30 @@ int hdp_thresholds_f32(const float *x, int64_t n_cells, int64_t T, int64_t strid
   std::unique_ptr<hdp_threshold_plan> guard(plan);
   if (n_cells == 0) return HDP_OK;
   const int64_t chunk = chunk_cells_for(n_cells, T * 4 + n_doy * P * 8);
-  DevBuf dx, dout, dref;
-  HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
+  DevBuf dx[2], dout, dref;
+  HDP_HIP_TRY(dx[0].alloc(size_t(chunk) * T * 4));
+  if (chunk < n_cells) HDP_HIP_TRY(dx[1].alloc(size_t(chunk) * T * 4));  // the next chunk uploads under this one's kernels
   HDP_HIP_TRY(dout.alloc(size_t(chunk) * n_doy * P * 8));
   HDP_HIP_TRY(dref.alloc(size_t(chunk) * n_doy * P * 8));
   SeriesUploader up;
   rc = up.prepare(x, n_cells, T, stride_cell, stride_time, whole_matrix_limit(), g_stream);
   if (rc != HDP_OK) return rc;
+  HDP_HIP_TRY(hipStreamSynchronize(g_stream));  // the upload stream reads what prepare() put on the device
+  AsyncUpload au;
+  rc = au.init();
+  if (rc != HDP_OK) return rc;
   ResultPrefault pre;
   pre.start(out, size_t(std::min(chunk, n_cells)) * n_doy * P * 8);
-  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
+  au.start(&up, x, 0, std::min(chunk, n_cells), T, stride_cell, stride_time, dx[0].as<float>());
+  int64_t k = 0;
+  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk, ++k) {
     const int64_t nc = std::min(chunk, n_cells - c0);
-    rc = up.upload(x, c0, nc, T, stride_cell, stride_time, dx.as<float>(), g_stream);
+    rc = au.wait();  // chunk k is on the device
     if (rc != HDP_OK) return rc;
-    rc = launch_thresholds(plan, dx.as<float>(), nc, dout.as<double>(), g_stream);
+    // dx[(k + 1) & 1] was last read by the kernels of chunk k - 1, finished before the previous iteration ended
+    if (c0 + nc < n_cells)
+      au.start(&up, x, c0 + nc, std::min(chunk, n_cells - c0 - nc), T, stride_cell, stride_time, dx[(k + 1) & 1].as<float>());
+    rc = launch_thresholds(plan, dx[k & 1].as<float>(), nc, dout.as<double>(), g_stream);
     if (rc != HDP_OK) return rc;
     // device layout [cell][P][n_doy] -> the reference's (cell, doy, percentile)
     rc = launch_swap_last2_f64(dout.as<double>(), nc, P, n_doy, dref.as<double>(), g_stream);
@@ -578,22 +641,32 @@ static int metrics_host_chunks(const float *x, int64_t n_cells, int64_t T, int64
   if (n_thr_cells < n_cells) {
     chunk = std::max<int64_t>(n_thr_cells, chunk / n_thr_cells * n_thr_cells);
   }
+  DevBuf dx2;  // the next chunk uploads under this one's kernels (see AsyncUpload)
   HDP_HIP_TRY(dx.alloc(size_t(chunk) * T * 4));
+  if (chunk < n_cells) HDP_HIP_TRY(dx2.alloc(size_t(chunk) * T * 4));
   HDP_HIP_TRY(dsouth.alloc(size_t(chunk)));
   HDP_HIP_TRY(dout.alloc(size_t(4) * P * D * chunk * Y * 2));
   SeriesUploader up;
   rc = up.prepare(x, n_cells, T, stride_cell, stride_time, whole_matrix_limit(), g_stream);
   if (rc != HDP_OK) return rc;
-  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
+  HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  AsyncUpload au;
+  rc = au.init();
+  if (rc != HDP_OK) return rc;
+  float *const dxs[2] = {dx.as<float>(), dx2.as<float>()};
+  au.start(&up, x, 0, std::min(chunk, n_cells), T, stride_cell, stride_time, dxs[0]);
+  int64_t k = 0;
+  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk, ++k) {
     const int64_t nc = std::min(chunk, n_cells - c0);
-    rc = up.upload(x, c0, nc, T, stride_cell, stride_time, dx.as<float>(), g_stream);
+    rc = au.wait();
     if (rc != HDP_OK) return rc;
+    if (c0 + nc < n_cells)
+      au.start(&up, x, c0 + nc, std::min(chunk, n_cells - c0 - nc), T, stride_cell, stride_time, dxs[(k + 1) & 1]);
     HDP_HIP_TRY(hipMemcpyAsync(dsouth.p, is_south + c0, size_t(nc), hipMemcpyHostToDevice, g_stream));
     // with shared thresholds c0 is a multiple of n_thr_cells, so the modulo mapping is unchanged
     const double *thr_base = dthr.as<double>() + (n_thr_cells == n_cells ? c0 * n_doy * P : 0);
     const int64_t ntc = (n_thr_cells == n_cells) ? nc : n_thr_cells;
-    rc = launch_metrics(plan, dx.as<float>(), thr_base, ntc, dsouth.as<uint8_t>(), nc, dout.as<int16_t>(),
-                        g_stream);
+    rc = launch_metrics(plan, dxs[k & 1], thr_base, ntc, dsouth.as<uint8_t>(), nc, dout.as<int16_t>(), g_stream);
     if (rc != HDP_OK) return rc;
     rc = sink(c0, nc, chunk, dout.as<int16_t>());
     if (rc != HDP_OK) return rc;

@@ -5,7 +5,8 @@ opening a variable from a netCDF file or zarr store, and latitude-band streaming
 The reference opens the whole variable lazily (dask) and lets the scheduler walk its chunks; here the
 same effect comes from slicing the lazily opened variable into bands of latitude rows, each of which
 is materialised, pushed through the HIP kernels and released before the next -- grid cells are
-independent, so bands need no halo.  Reading and writing need xarray (with netCDF4 / zarr); neither
+independent, so bands need no halo.  Band k + 1 is read on a helper thread while band k computes (``iter_bands``), and
+inside a band the library uploads chunk c + 1 under the kernels of chunk c (AsyncUpload in hdp_api.hip).  Reading and writing need xarray (with netCDF4 / zarr); neither
 is in the build image, so the flow is tested with an in-memory stand-in (tests/test_io_cpu.py).
 """
 from __future__ import annotations
@@ -69,6 +70,39 @@ def lat_slices(n_lat: int, lat_band):
     if lat_band < 1:
         raise ValueError("lat_band must be a positive number of latitude rows")
     return [(a, min(a + lat_band, n_lat)) for a in range(0, n_lat, lat_band)]
+
+
+def iter_bands(variables, slices, dim="lat"):
+    """Yield, for every [a, b) of ``slices``, the tuple of ``v.isel(dim=slice(a, b))`` for v in ``variables`` -- with
+    band k + 1 being read from its file / store (``.load()`` of a lazily opened variable) on a helper thread while the
+    caller pushes band k through the GPU.  ctypes releases the GIL for the library calls, so the read of the next band,
+    the upload of the next chunk (the library's own upload thread) and the kernels of the current chunk all overlap;
+    at most two bands are in host memory at a time."""
+    import threading
+
+    def fetch(a, b, box):
+        try:
+            band = tuple(v.isel(**{dim: slice(a, b)}) for v in variables)
+            box.append(tuple(x.load() if hasattr(x, "load") else x for x in band))
+        except BaseException as e:      # noqa: BLE001 -- re-raised by the consumer
+            box.append(e)
+
+    slices = list(slices)
+    nxt, th = [], None
+    if slices:
+        fetch(*slices[0], nxt)
+    for k in range(len(slices)):
+        cur = nxt[0]
+        if isinstance(cur, BaseException):
+            raise cur
+        nxt = []
+        if k + 1 < len(slices):
+            th = threading.Thread(target=fetch, args=(*slices[k + 1], nxt), daemon=True)
+            th.start()
+        yield cur
+        if th is not None:
+            th.join()
+            th = None
 
 
 def concat_lat(parts):

@@ -63,9 +63,8 @@ def compute_individual_metrics(measure, threshold, hw_definitions, include_thres
     if blocks is not None and blocks[0] in threshold.dims:
         # lazily chunked measure: one block at a time with the matching slice of the thresholds (metric.py:444)
         dim, edges = blocks
-        parts = [compute_individual_metrics(measure.isel(**{dim: slice(a, b)}), threshold.isel(**{dim: slice(a, b)}),
-                                            hw_definitions, include_threshold, check_variables, shard)
-                 for a, b in edges]
+        parts = [compute_individual_metrics(m_blk, t_blk, hw_definitions, include_threshold, check_variables, shard)
+                 for m_blk, t_blk in hio.iter_bands((measure, threshold), edges, dim)]
         return hio.concat_dim(parts, dim)
     xr = backend()
     times = np.asarray(measure.coords["time"].values)
@@ -227,9 +226,8 @@ def compute_metrics_io(output_path: str, measure_path: str, measure_var: str, th
     if lat_band and "lat" in measure_data.dims:
         n_lat = measure_data.shape[list(measure_data.dims).index("lat")]
         parts = []
-        for a, b in hio.lat_slices(n_lat, lat_band):
-            parts.append(compute_individual_metrics(measure_data.isel(lat=slice(a, b)),
-                                                    threshold_data.isel(lat=slice(a, b)), hw_definitions,
+        for m_band, t_band in hio.iter_bands((measure_data, threshold_data), hio.lat_slices(n_lat, lat_band)):
+            parts.append(compute_individual_metrics(m_band, t_band, hw_definitions,
                                                     include_threshold=include_threshold,
                                                     check_variables=check_variables))
         metric_ds = hio.concat_lat(parts)

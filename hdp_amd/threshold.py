@@ -50,8 +50,9 @@ def compute_threshold(baseline_data, percentiles, no_season: bool = False, rolli
     blocks = hio.block_slices(baseline_data, skip=("time", "member"))
     if blocks is not None:   # lazily chunked input: one block at a time, as the reference's map_blocks does
         dim, edges = blocks
-        parts = [compute_threshold(baseline_data.isel(**{dim: slice(a, b)}), percentiles, no_season,
-                                   rolling_window_size, fixed_value, shard) for a, b in edges]
+        # block k + 1 is read (dask: computed) on a helper thread while block k is on the GPU
+        parts = [compute_threshold(blk, percentiles, no_season, rolling_window_size, fixed_value, shard)
+                 for (blk,) in hio.iter_bands((baseline_data,), edges, dim)]
         return hio.concat_dim(parts, dim)
     xr = backend()
     dims = list(baseline_data.dims)
@@ -138,8 +139,7 @@ def compute_threshold_io(baseline_path: str, baseline_var: str, output_path: str
     if lat_band and "lat" in baseline_data.dims:
         n_lat = baseline_data.shape[list(baseline_data.dims).index("lat")]
         parts = []
-        for a, b in hio.lat_slices(n_lat, lat_band):
-            band = baseline_data.isel(lat=slice(a, b))
+        for (band,) in hio.iter_bands((baseline_data,), hio.lat_slices(n_lat, lat_band)):
             parts.append(compute_threshold(band, percentiles, no_season, rolling_window_size, fixed_value))
         threshold_ds = hio.concat_lat(parts)
     else:

@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 import hdp_amd.metric  # noqa: E402
 import hdp_amd.threshold  # noqa: E402
-from hdp_amd import utils  # noqa: E402
+from hdp_amd import calendar as cal, core, utils  # noqa: E402
+from oracle import c_oracle  # noqa: E402
 from oracle import hdp_oracle as orc  # noqa: E402
 from tests.helpers import measure_dataset  # noqa: E402
 
@@ -175,3 +176,74 @@ def test_io_wrappers_band_streaming_on_the_device(tmp_path, monkeypatch):
         a, b = files[str(tmp_path / "hw.nc")][name], files[str(tmp_path / "hw_b.nc")][name]
         assert tuple(a.dims) == tuple(b.dims) and np.array_equal(a.values, b.values) and a.values.sum() >= 0
     assert files[str(tmp_path / "hw.nc")]["HWF"].values.sum() > 0
+    # ... and both are what the ORACLE computes from the same arrays (not only each other): thresholds bit for bit,
+    # metrics as the int64 planes (percentile, definition, lon, lat, year)
+    xb = base.astype(np.float32).reshape(-1, base.shape[-1])
+    want_thr = orc.compute_thresholds_cells(xb, orc.datetimes_to_windows(bdates, 7), q)          # [cells, doy, P]
+    assert np.array_equal(banded["temp_threshold"].values.reshape(want_thr.shape), want_thr)
+    north, south, _ = orc.hemisphere_ranges(mdates)
+    is_south = np.repeat((lat < 0)[None, :], base.shape[0], axis=0).reshape(-1)
+    xm = warm.astype(np.float32).reshape(-1, warm.shape[-1])
+    want = orc.compute_metrics_cells(xm, want_thr, orc.build_doy_map(mdates), defs, north, south, is_south)  # [P, D, n, 4, Y]
+    for i, name in enumerate(("HWF", "HWN", "HWD", "HWA")):
+        got = files[str(tmp_path / "hw_b.nc")][name].values                                       # [P, D, lon, lat, Y]
+        assert got.dtype == np.int64 and np.array_equal(got.reshape(want.shape[0], want.shape[1], -1, want.shape[4]),
+                                                        want[:, :, :, i, :])
+
+
+def test_chunked_inputs_walk_block_by_block_on_the_device():
+    """SURVEY 8f row 3 on the GPU: inputs that expose dask-style ``.chunks`` are pushed through the kernels one block at
+    a time (the next block fetched on a helper thread meanwhile) and give what the oracle computes for the whole grid."""
+    base, lon, lat, bdates = utils.generate_control_array(start_date="1700-01-01", end_date="1707-12-31",
+                                                          grid_shape=(4, 9), add_noise=True, seed=11)
+    warm, _, _, mdates = utils.generate_warming_array(start_date="2000-01-01", end_date="2007-12-31",
+                                                      grid_shape=(4, 9), add_noise=True)
+    q = [0.9, 0.93, 0.99]
+    defs = [[3, 0, 0], [2, 1, 1], [4, 2, 2]]
+    bda = measure_dataset(base, lon, lat, bdates)["temp"]                  # dims (lon, lat, time)
+    bda.chunks = ((4,), (2, 3, 4), (bdates.size,))                          # three ragged blocks along lat
+    thr = hdp_amd.threshold.compute_threshold(bda, q)
+    xb = base.astype(np.float32).reshape(-1, base.shape[-1])
+    want_thr = orc.compute_thresholds_cells(xb, orc.datetimes_to_windows(bdates, 7), q)
+    assert np.array_equal(thr["temp_threshold"].values.reshape(want_thr.shape), want_thr)
+    mda = measure_dataset(warm, lon, lat, mdates)["temp"]
+    mda.chunks = ((1, 3), (9,), (mdates.size,))                             # two blocks along lon
+    got = hdp_amd.metric.compute_individual_metrics(mda, thr["temp_threshold"], defs, check_variables=False)
+    north, south, _ = orc.hemisphere_ranges(mdates)
+    is_south = np.repeat((lat < 0)[None, :], base.shape[0], axis=0).reshape(-1)
+    xm = warm.astype(np.float32).reshape(-1, warm.shape[-1])
+    want = orc.compute_metrics_cells(xm, want_thr, orc.build_doy_map(mdates), defs, north, south, is_south)
+    for i, name in enumerate(("HWF", "HWN", "HWD", "HWA")):
+        assert np.array_equal(got[name].values.reshape(want.shape[0], want.shape[1], -1, want.shape[4]), want[:, :, :, i, :])
+
+
+@pytest.mark.timeout(600)
+def test_host_pointer_calls_with_several_chunks_match_one_chunk(monkeypatch):
+    """The host-pointer entry points stream the series through the device in chunks, chunk k + 1 uploading (helper
+    thread, second stream, second device buffer) under the kernels of chunk k: a call cut into many chunks returns
+    exactly what a one-chunk call returns, for time-contiguous, time-major and arbitrarily strided inputs."""
+    rng = np.random.default_rng(21)
+    dates = utils.noleap_date_range("2001-01-01", "2008-12-31")
+    T, n = dates.size, 300000 // 8                       # 37 500 series x 2 920 days = 438 MB: one chunk of the 1 GiB budget
+    x = rng.normal(15, 4, size=(n, T)).astype(np.float32)
+    ti, cols = cal.window_columns(dates, 7)
+    q = [0.9, 0.95]
+    dm = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    hemi = (np.arange(n) % 2).astype(np.uint8)
+    defs = [[3, 0, 0], [3, 1, 1]]
+    thr1 = core.compute_percentiles(x, ti, cols, q)
+    met1 = core.compute_heatwave_metrics(x, thr1, dm, defs, north, south, hemi)
+    pick = np.arange(0, n, n // 48)
+    want_thr = c_oracle.thresholds(x[pick], cal.expand_window_table(ti, cols), q)
+    assert np.array_equal(thr1[pick], want_thr)
+    assert np.array_equal(met1[:, :, pick].astype(np.int64),
+                          c_oracle.metrics(x[pick], want_thr, dm, defs, north, south, hemi[pick]))
+    big = np.concatenate([x] * 4)                        # 1.75 GB: several chunks, double-buffered
+    thr4 = core.compute_percentiles(big, ti, cols, q)
+    assert all(np.array_equal(thr4[i * n:(i + 1) * n], thr1) for i in range(4))
+    met4 = core.compute_heatwave_metrics(big, thr4, dm, defs, north, south, np.tile(hemi, 4))
+    assert all(np.array_equal(met4[:, :, i * n:(i + 1) * n], met1) for i in range(4))
+    wide = np.empty((4 * n, T + 3), dtype=np.float32)    # a padded row pitch: packed on the host, chunk by chunk
+    wide[:, :T] = big
+    assert np.array_equal(core.compute_percentiles(wide[:, :T], ti, cols, q), thr4)
