@@ -533,6 +533,10 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   pl->opt_years = (int32_t)env_option("HDP_METRICS_YEARS", 1);   // 0: never, 1: records of >= 24 years, 2: any length
   pl->opt_years_lds = (int32_t)std::min<long long>(65536, std::max<long long>(0, env_option("HDP_METRICS_YEARS_LDS", 16384)));
   pl->opt_batch = std::max<long long>(0, env_option("HDP_METRICS_BATCH", 0));
+  {  // queue entries per lane of metrics_kernel_cells16q (32, 48 or 64); 0: the lock-step kernel
+    const long long qv = env_option("HDP_METRICS_QUEUE", 0);
+    pl->opt_queue = qv <= 0 ? 0 : (qv >= 64 ? 64 : (qv >= 48 ? 48 : 32));
+  }
   pl->opt_simple = env_option("HDP_METRICS_SIMPLE", 1) != 0;   // short path for pairs of definitions with max_break = 0
   pl->Ypitch = (Y + 15) & ~int64_t(15);  // 32-byte rows: sector-aligned packed stores
   int64_t dmax = 1;

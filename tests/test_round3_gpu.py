@@ -161,3 +161,55 @@ def test_c5_ensemble_4096_cells_properties_and_oracle_sample():
     hemi = np.tile((lat[idx] < 0).astype(np.uint8), M)
     met_c = c_oracle.metrics(xs_m, np.concatenate([th_g] * M), dm, DEFS, north, south, hemi)
     assert np.array_equal(met_g, met_c)
+
+
+# ---- metrics_kernel_cells16q: per-lane pace between season closings (lane-private run queues in LDS) ----------------
+from tests.test_round2_gpu import _regular_case  # noqa: E402
+
+
+@pytest.mark.parametrize("cap", [32, 48, 64])
+@pytest.mark.parametrize("n_doy,T,P,defs", [
+    (365, 365 * 9, 10, [[3, 0, 0], [3, 1, 1], [4, 0, 0], [4, 1, 1], [5, 0, 0], [5, 1, 1]]),
+    (365, 365 * 40 + 17, 10, [[3, 0, 0], [3, 1, 1], [5, 2, 2]]),
+    (365, 365 * 8 + 63, 2, [[25, 1, 1], [30, 0, 0]]),
+    (360, 360 * 7 + 200, 4, [[3, 0, 0], [40, 2, 1]]),
+    (365, 365 * 26, 4, [[3, 0, 0], [4, 0, 0], [5, 0, 0], [6, 0, 0]]),      # every pair simple: nothing is ever "near"
+    (365, 365 * 12, 3, [[1, 0, 0], [0, 3, 1], [2, 5, 0], [1, 1, 3]]),      # min_duration 0/1: every run is kept; long breaks
+    (365, 365 * 30, 2, [[3, 40, 2], [6, 2, 0], [2, 0, 0]]),               # a 40-day max_break keeps far-apart short runs
+])
+def test_queued_state_machines_match_the_oracle_and_the_lock_step_kernel(cap, n_doy, T, P, defs, monkeypatch):
+    monkeypatch.setenv("HDP_METRICS_YEARS", "2")
+    case = _regular_case(7000 + n_doy + P + len(defs), n_doy, T, 70, P, defs, long_runs=True)
+    x, thr, doy_map, dfs, north, south, is_south = case
+    want = c_oracle.metrics(x, thr, doy_map, dfs, north, south, is_south)
+    lock = core.compute_heatwave_metrics(*case)
+    assert np.array_equal(lock.astype(np.int64), want)
+    monkeypatch.setenv("HDP_METRICS_QUEUE", str(cap))
+    got = core.compute_heatwave_metrics(*case)
+    assert np.array_equal(got, lock), (cap, n_doy, T, P, defs)
+    monkeypatch.setenv("HDP_METRICS_YEARS", "0")      # day-aligned words (any calendar) through the same kernel
+    assert np.array_equal(core.compute_heatwave_metrics(*case), lock)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_queued_state_machines_random_sweep(seed, monkeypatch):
+    """Dense exceedance (queues fill up inside a year and inside a word), random definitions incl. large max_break."""
+    rng = np.random.default_rng(12000 + seed)
+    n_doy = int(rng.choice([365, 365, 360, 366, int(rng.integers(321, 385))]))
+    years = int(rng.choice([3, 9, 26, 40]))
+    T = min(65535, years * n_doy + int(rng.choice([0, 1, 63, 64, 200])))
+    P = int(rng.integers(1, 12))
+    D = int(rng.integers(1, 9))
+    defs = [[int(rng.integers(0, 7)), 0 if rng.random() < 0.4 else int(rng.integers(1, 9)), int(rng.integers(0, 4))]
+            for _ in range(D)]
+    case = list(_regular_case(12100 + seed, n_doy, T, 67, P, defs, long_runs=bool(seed & 1)))
+    case[1] = np.sort(rng.normal(-0.2 + 0.5 * rng.random(), 0.5, size=case[1].shape), axis=2)   # hot about half the time
+    x, thr, doy_map, dfs, north, south, is_south = case
+    if north.shape[0] == 0:
+        pytest.skip("no complete season in this record")
+    want = c_oracle.metrics(x, thr, doy_map, dfs, north, south, is_south)
+    monkeypatch.setenv("HDP_METRICS_YEARS", "2")
+    for cap in (32, 64):
+        monkeypatch.setenv("HDP_METRICS_QUEUE", str(cap))
+        got = core.compute_heatwave_metrics(*case)
+        assert np.array_equal(got.astype(np.int64), want), (cap, n_doy, T, P, defs)
