@@ -534,8 +534,12 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   pl->opt_years_lds = (int32_t)std::min<long long>(65536, std::max<long long>(0, env_option("HDP_METRICS_YEARS_LDS", 16384)));
   pl->opt_batch = std::max<long long>(0, env_option("HDP_METRICS_BATCH", 0));
   {  // queue entries per lane of metrics_kernel_cells16q (32, 48 or 64); 0: the lock-step kernel
+#ifdef HDP_PROTO_QUEUE
     const long long qv = env_option("HDP_METRICS_QUEUE", 0);
     pl->opt_queue = qv <= 0 ? 0 : (qv >= 64 ? 64 : (qv >= 48 ? 48 : 32));
+#else
+    pl->opt_queue = 0;  // the prototype kernel is not in this build
+#endif
   }
   pl->opt_simple = env_option("HDP_METRICS_SIMPLE", 1) != 0;   // short path for pairs of definitions with max_break = 0
   pl->Ypitch = (Y + 15) & ~int64_t(15);  // 32-byte rows: sector-aligned packed stores
@@ -854,7 +858,8 @@ const char *hdp_metrics_plan_describe(const hdp_metrics_plan *plan) {
     snprintf(buf, sizeof buf, "%s + metrics_kernel_cells%s (lane = series; batches of series, the two kernels of "
              "consecutive batches overlap on the plan's streams)",
              hdp::metrics_year_words(plan) ? "exceed_years_kernel" : (plan->opt_pairs ? "exceed_pairs_kernel" : "exceed_kernel"),
-             (plan->defs_fit16 && plan->T <= 65535 && plan->opt_packed) ? "16 (packed 16-bit state)" : "");
+             (plan->defs_fit16 && plan->T <= 65535 && plan->opt_packed)
+                 ? (plan->opt_queue ? "16q (packed 16-bit state, lane-private run queues)" : "16 (packed 16-bit state)") : "");
   return buf;
 }
 

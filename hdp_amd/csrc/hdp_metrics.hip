@@ -1264,7 +1264,14 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
-// ---- the packed kernel with per-lane pace between season closings (round 3) ------------------------------------
+#ifdef HDP_PROTO_QUEUE
+// ---- the packed kernel with per-lane pace between season closings (round 3 prototype) -------------------------------
+// MEASURED AND NOT ADOPTED (profiles/r03_metrics_queue*): 13.1 ms against the lock-step kernel's 9.4 ms per 65 536 series
+// at 32 queue entries per lane, 15.2 at 48, 21.8 at 64.  PMC: 2.31e9 vector instructions per launch against 1.87e9 --
+// phase A costs ~45 vector + ~30 scalar instructions a trip once it is a loop of its own (three nested exec-mask regions),
+// phase B ~90, so a mean run costs 45 x 2.0 + 90 x 1.5 = 225 against the fused trip's 97 x 2.0 = 194 -- and the queues
+// (8 KB per wave at 32 entries) cut the resident waves from 20 to 12 per CU.  Built only with -DHDP_PROTO_QUEUE
+// (`make EXTRA=-DHDP_PROTO_QUEUE`), selected with HDP_METRICS_QUEUE=32|48|64; tests/test_round3_gpu.py runs it when built.
 // metrics_kernel_cells16 walks a word's runs in lock step: a trip of its inner loop extracts ONE run per lane and steps every
 // definition's state machine with it, so a word costs (the maximum over the 64 series of the runs in that word) trips of
 // ~116 vector instructions -- 1.85x the mean lane's runs on the bench's exceedance words.  Here the two halves of a trip
@@ -1537,6 +1544,8 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
     while (si < Y) finalize(false);
   }
 }
+
+#endif  // HDP_PROTO_QUEUE
 
 // Row layout of the (percentile, definition)-per-lane kernels, [planes][nc][Ypitch], -> device layout
 // [planes][Y][n_total] at series offset cell_off.  One workgroup per (plane, 64 series), through LDS.
@@ -2319,6 +2328,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
                  plan->defs16_host[3 * (d0 + 2 * ns) + 1] == 0 &&
                  (d0 + 2 * ns + 1 >= md.D || plan->defs16_host[3 * (d0 + 2 * ns + 1) + 1] == 0))
             ++ns;
+#ifdef HDP_PROTO_QUEUE
           const int qcap = plan->opt_queue;  // > 0: per-lane pace between season closings (metrics_kernel_cells16q)
           const size_t lds_q = lds_c + size_t(kMetWaves) * 64 * 4 * size_t(qcap > 0 ? qcap : 0);
 #define HDP_C16_CASE(NPV, NSV)                                                                                              \
@@ -2336,6 +2346,9 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     else                                                                                                                    \
       hipLaunchKernelGGL((metrics_kernel_cells16<NPV, NSV>), g16, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev, d0);    \
   } while (0)
+#else
+#define HDP_C16_CASE(NPV, NSV) hipLaunchKernelGGL((metrics_kernel_cells16<NPV, NSV>), g16, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev, d0)
+#endif
           switch (dg * 4 + ns) {
             case 2 * 4 + 0: HDP_C16_CASE(1, 0); break;
             case 2 * 4 + 1: HDP_C16_CASE(1, 1); break;
