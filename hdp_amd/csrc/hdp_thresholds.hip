@@ -10,15 +10,20 @@
 // out of its W sorted columns and interpolate in float64 with numba's operation order,
 // lower*(1-m) + upper*m, no FMA contraction (this file is compiled with -ffp-contract=off).
 //
-// Three kernels, same results bit for bit (tests/test_thresholds_kernels_gpu.py):
-//   thresholds_pipe_kernel<LPC, VEC, NG>   S <= 128 (the headline config: S = 100).  Persistent
-//             workgroups, waves specialised: producers gather a block's columns straight from
-//             HBM into registers and sort them there (DPP rows, v_med3), merging waves run a
-//             W-way merge per row (one lane per row) out of the LDS image of the previous block.
+// Four kernels, same results bit for bit (tests/test_thresholds_kernels_gpu.py); the plan picks one (thr_variant):
+//   thresholds_lane_kernel<N, NG, TIER, ROWS>   S <= 100, W <= 16 -- the headline config (S = 100, W = 15).  One LANE sorts
+//             one column in N registers (Batcher merge exchange, nothing crosses lanes); merging waves run a W-way
+//             merge per row (one lane per row) out of the LDS image of the previous item.  ROWS = 384 ("whole cell"): all
+//             365 columns and all 365 merge chains of a cell in one 12-wave workgroup per CU, the image tiered (top 60
+//             samples of a column in LDS, the rest in a per-workgroup global tail); ROWS = 128: blocks of rows, untiered.
+//   thresholds_pipe_kernel<LPC, VEC, NG>   100 < S <= 128, or windows wider than 16 columns.  Persistent workgroups,
+//             waves specialised: producers gather a block's columns straight from HBM into registers and sort them
+//             there (16-lane DPP rows, v_med3), merging waves as above.
 //   thresholds_kernel<EPL, false>          any S <= 2048: one workgroup per cell, load -> LDS,
 //             wave sort (lane-major bitonic network), W-way merge per row.
 //   thresholds_kernel<EPL, true>           the same with a rank SELECTION per (row, requested
 //             rank) instead of the merge, for deep ranks (10-member ensemble: S = 1000).
+// plus table_percentiles_kernel, the literal [n_doy, B] table path of the reference's gufunc operands (unit-level parity).
 //
 // This path is VALU/LDS (sort + merge) work, not MFMA work; its roofline is HBM bandwidth:
 // algorithmic bytes per cell = 4*T (read) + 8*n_doy*P (write).
@@ -2267,12 +2272,14 @@ int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, 
     // the copy stream gets the highest priority: its workgroups are dispatched ahead of the next chunk's kernel
     int prio_lo = 0, prio_hi = 0;
     HDP_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HDP_HIP_TRY(hipStreamCreateWithPriority(&plan->tm_stream, hipStreamNonBlocking, prio_hi));
-    HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_fork, hipEventDisableTiming));
+    // events first, the stream last: `tm_stream != nullptr` then means "everything exists" -- a failure half way leaves
+    // tm_stream null, the next call starts over (an event that already exists is kept), the destructor frees the rest
+    if (!plan->tm_fork) HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_fork, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
-      HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_copied[i], hipEventDisableTiming));
-      HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_used[i], hipEventDisableTiming));
+      if (!plan->tm_copied[i]) HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_copied[i], hipEventDisableTiming));
+      if (!plan->tm_used[i]) HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_used[i], hipEventDisableTiming));
     }
+    HDP_HIP_TRY(hipStreamCreateWithPriority(&plan->tm_stream, hipStreamNonBlocking, prio_hi));
   }
   const size_t need = 2 * size_t(chunk) * T * 4;
   if (plan->tm_stage.bytes < need) {

@@ -91,8 +91,14 @@ int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_doy, int64_t 
                               const double *q, int64_t P, int64_t T,
                               hdp_threshold_plan **plan_out);
 int hdp_threshold_plan_destroy(hdp_threshold_plan *plan);
-/* Human-readable name and shape of the kernel a launch of this plan runs now (the plan's choice
- * under the HDP_THR_* environment switches); thread-local storage, valid until the next call. */
+/* Human-readable name and shape of the kernel a launch of this plan runs (the HDP_THR_* environment switches are
+ * read ONCE, when the plan is created, never at launch); thread-local storage, valid until the next call.
+ *
+ * Concurrency: a plan owns scratch that its launches write (the tiered image's global tail of the whole-cell kernel,
+ * the staging buffers, copy stream and events of the time-major path) -- ONE launch of a plan in flight at a time.
+ * Launches of one plan on one stream are ordered and safe; two streams or two host threads need two plans.  The
+ * first launch of a plan may allocate that scratch (a stream synchronisation + hipMalloc); later launches with no
+ * more cells than any earlier one allocate nothing. */
 const char *hdp_threshold_plan_describe(const hdp_threshold_plan *plan);
 
 /* x_dev [n_cells][T] float32 time-contiguous -> out_dev [n_cells][P][n_doy] float64.
