@@ -217,7 +217,7 @@ int launch_weighted_row_mean_i16(const int16_t *v_dev, int64_t n_rows, int64_t n
 int launch_weighted_row_mean_f64(const double *v_dev, int64_t n_rows, int64_t n, const double *w_dev,
                                  double *out_dev, hipStream_t stream);
 int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
-                     hipStream_t stream);
+                     hipStream_t stream, bool beside_state_machines = false);
 int launch_swap_last2_f64(const double *src_dev, int64_t n, int64_t A, int64_t B, double *dst_dev,
                           hipStream_t stream);
 int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,

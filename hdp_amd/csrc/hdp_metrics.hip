@@ -1918,12 +1918,61 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
   }
 }
 
+// The same copy with NL loads per thread in flight (round 3).  The copy runs BESIDE the kernel that consumes the
+// previous chunk: the whole-cell thresholds kernel leaves a CU 20 KB of LDS and 80 registers per SIMD, the packed state
+// machines 32 registers per SIMD -- room for one or two of these workgroups, and a workgroup of the kernel above has only
+// 8 KB in flight per load-barrier-store round trip (~1.5 TB/s chip-wide at two per CU: slower than the kernel it was
+// meant to hide behind).  Here a thread first issues all its NL loads (4 NL time steps x 64 cells = NL KB per
+// workgroup, landing in registers), then feeds them through the same 8.3 KB tile 32 time steps at a time.
+template <int NL>
+__global__ __launch_bounds__(256) void transpose_mlp_kernel(const float *__restrict__ src, int64_t src_pitch,
+                                                            int64_t T, int64_t n, float *__restrict__ dst) {
+  static_assert(NL % 8 == 0, "sub-tiles of 32 time steps");
+  __shared__ float tile[32][65];
+  const int64_t t0 = int64_t(blockIdx.y) * (4 * NL), c0 = int64_t(blockIdx.x) * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;  // 64 cells x 4 time steps per load instruction
+  const bool cok = c0 + lx < n;
+  float v[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int64_t t = t0 + ly + 4 * i;
+    v[i] = (cok && t < T) ? src[t * src_pitch + c0 + lx] : 0.0f;
+  }
+  const int tx = threadIdx.x & 31, cy = threadIdx.x >> 5;  // 32 time steps x 8 cells per store instruction
+#pragma unroll
+  for (int s = 0; s < NL / 8; ++s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tile[ly + 4 * i][lx] = v[8 * s + i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t c = c0 + cy + 8 * i, t = t0 + 32 * s + tx;
+      if (t < T && c < n) dst[c * T + t] = tile[tx][cy + 8 * i];
+    }
+    __syncthreads();
+  }
+}
+
+// `beside_state_machines`: the copy will run next to the packed state machines, which leave 32 registers per SIMD -- the
+// 10-register kernel; otherwise (next to the whole-cell thresholds kernel: 80 registers per SIMD, or on an idle device)
+// 48 loads in flight per thread.  Measured on 109 795 cells, three chunks (profiles/r03_tm_*): thresholds pass 23.1 ms
+// with the 8-load kernel, 21.2 / 20.8 ms with 24 / 48 loads; metrics pass 22.3 / 23.2 / 23.2 ms.
 int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
-                     hipStream_t stream) {
+                     hipStream_t stream, bool beside_state_machines) {
   if (T * n == 0) return HDP_OK;
-  dim3 grid((unsigned)((n + 63) / 64), (unsigned)((T + 31) / 32));
+  static const int nl_env = (int)env_option("HDP_TM_LOADS", -1);  // loads in flight per thread (0: the 8-load kernel); A/B only
+  const int nl = nl_env >= 0 ? nl_env : (beside_state_machines ? 0 : 48);
+  const int tsteps = nl >= 48 ? 192 : (nl >= 24 ? 96 : (nl >= 16 ? 64 : 32));
+  dim3 grid((unsigned)((n + 63) / 64), (unsigned)((T + tsteps - 1) / tsteps));
   HDP_REQUIRE(grid.y < 65536, HDP_EUNSUP, "time axis too long for the transpose launch");
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+  if (nl >= 48)
+    hipLaunchKernelGGL(transpose_mlp_kernel<48>, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+  else if (nl >= 24)
+    hipLaunchKernelGGL(transpose_mlp_kernel<24>, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+  else if (nl >= 16)
+    hipLaunchKernelGGL(transpose_mlp_kernel<16>, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+  else
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
 }
@@ -2275,7 +2324,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
       // this half of the scratch is free once the state machine of batch b - 2 has read it
       if (overlap && b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_state[half], 0));
       if (tm) {  // staging half `half` was last read by the exceedance kernel of batch b - 2, earlier on this stream
-        const int rc = launch_transpose(x_dev + c0, tm_pitch, md.T, nc, const_cast<float *>(x_b), sx);
+        const int rc = launch_transpose(x_dev + c0, tm_pitch, md.T, nc, const_cast<float *>(x_b), sx, true);
         if (rc != HDP_OK) return rc;
       }
       if (HDP_MDBG(md, 8)) {  // ablation builds: state machines only, on the exceedance words of the previous call
