@@ -11,7 +11,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhdp_hip.so")
+# HDP_LIB_PATH: an instrumented build of the same library (make EXTRA=-DHDP_DEBUG_ABLATIONS LIB=...), development only
+LIB_PATH = os.environ.get("HDP_LIB_PATH") or os.path.join(_HERE, "libhdp_hip.so")
 
 HDP_OK = 0
 ERROR_NAMES = {-1: "HDP_EINVAL", -2: "HDP_ENODEV", -3: "HDP_EHIP", -4: "HDP_ENOMEM",

@@ -59,10 +59,10 @@ struct ThrDev {
   // HDP_THR_DEBUG and carries none of this code).  Bit mask; results are wrong under 1, 2, 4:
   //   1 no merge, 2 no sort, 4 no sample loads, 8 phase clocks of the one-workgroup-per-cell kernel (forces it),
   //   32 phase clocks of the pipelined kernel (merging wave / first producer), 512 with 32: start-up and step
-  //   loop of the merge instead of the producer phases, 64 roles by wave number instead of by SIMD,
+  //   loop of the merge instead of the producer phases, 64 roles by wave number instead of by SIMD, 1024 busy ticks of every wave of the lane kernel (by role rank),
   //   4096 print the kernel variant chosen.  The clocks cost about 10 % and serialise on global atomics.
   int debug;
-  unsigned long long *clk;  // [8] accumulated s_memtime ticks (debug & 8, debug & 32)
+  unsigned long long *clk;  // [8] accumulated s_memtime ticks (debug & 8, debug & 32); [8 + rank] busy ticks per wave (debug & 1024)
   long long grid_override;  // HDP_THR_GRID as read at plan creation (0: the occupancy-derived grid)
 };
 
@@ -838,7 +838,7 @@ __device__ __forceinline__ uint32_t lds_u32(uint32_t addr) {
 template <bool TOP, int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
                                                const float *tail_cur, const uint16_t *cl, int r, const RowFlags &rf,
-                                               double *orow, const TgtLanes &tl) {
+                                               double *orow, const TgtLanes &tl, int prio_phase = -1) {
   static_assert(NG >= 1 && NG <= 4, "group id is two payload bits");
   const int steps = TOP ? pd.steps_top : pd.steps_bot;
   const int nt = TOP ? pd.nt_top : pd.nt_bot;
@@ -989,13 +989,29 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
       emit_targets<TOP, true>(pd, tgt, nt, k, next_rank, step, __double2hiint(m[0]), __double2hiint(prev), rf, true, orow);
 #endif
     next_rank = __builtin_amdgcn_readfirstlane(next_rank);
+#ifndef HDP_MERGE_UNFAIR
+    // Two merging waves share a SIMD on half of a CU (six merging waves, four SIMDs).  At equal priority the issue
+    // arbiter serves the OLDER wave first, and the younger one's 151-step chain came out 15 % longer (70.7 k against
+    // 61 k cycles per cell, measured per wave: HDP_THR_DEBUG=1024) -- the whole workgroup waits for it at the barrier.
+    // The two therefore trade places every 16 steps: the wave whose turn it is runs at priority 3, the other at 2.
+    if (prio_phase >= 0) {  // wave-uniform
+#ifndef HDP_MERGE_BIAS
+#define HDP_MERGE_BIAS 2
+#endif
+      // the younger wave (prio_phase 1) is favoured in HDP_MERGE_BIAS of every 4 sixteen-step slices
+      const bool young_turn = ((step >> 4) & 3) < HDP_MERGE_BIAS;
+      if (young_turn == (prio_phase == 1)) __builtin_amdgcn_s_setprio(3);
+      else __builtin_amdgcn_s_setprio(2);
+    }
+#endif
   }
 }
 
 template <int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
                                                 const float *tail_cur, const uint32_t *flags, const uint16_t *cl, int r,
-                                                double *orow, const TgtLanes &tl_top, const TgtLanes &tl_bot) {
+                                                double *orow, const TgtLanes &tl_top, const TgtLanes &tl_bot,
+                                                int prio_phase = -1) {
   RowFlags rf{0, 0};
   uint32_t nan_or = 0;
 #pragma unroll
@@ -1006,8 +1022,9 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
     rf.n_neg += f & 0x7fff;
   }
   if (nan_or >> 31) rf.n_pos = -1;
-  merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_top);
-  merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_bot);
+  merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_top, prio_phase);
+  merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_bot, prio_phase);
+  if (prio_phase >= 0) __builtin_amdgcn_s_setprio(3);
 }
 
 // ---- rank selection (many samples per column) ---------------------------------------------------
@@ -1719,7 +1736,8 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
       uint32_t *flags_p = flags0 + int(s & 1) * flags_pitch;  // census of block s (double-buffered by parity)
       unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
       const bool clocked = HDP_DBG(pd, 32) && lane == 0 && pw == 0;
-      if (clocked) c0 = __builtin_readcyclecounter();
+      const bool clocked_w = HDP_DBG(pd, 1024) && lane == 0;
+      if (clocked || clocked_w) c0 = __builtin_readcyclecounter();
       // S as a value made inside the loop: everything derived from it (which slots are padding, where they are
       // written) is then recomputed per item with scalar instructions instead of being hoisted into registers
       int S_rt = pd.S;
@@ -1786,7 +1804,8 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
           }
         }
       }
-      if (clocked) c2 = __builtin_readcyclecounter();
+      if (clocked || clocked_w) c2 = __builtin_readcyclecounter();
+      if (clocked_w) atomicAdd(&pd.clk[8 + rank], c2 - c0);
       __syncthreads();  // image free (merge s-1 done), keys of block s sorted
       if (clocked) c3 = __builtin_readcyclecounter();
       if (s < n_items) {
@@ -1849,18 +1868,26 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
       const uint32_t *flags_m = flags0 + int((s + 1) & 1) * flags_pitch;  // census of block s - 1
       unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
       const bool clocked = HDP_DBG(pd, 32) && lane == 0 && rank == 0;
-      if (clocked) c0 = __builtin_readcyclecounter();
+      const bool clocked_w = HDP_DBG(pd, 1024) && lane == 0;
+      if (clocked || clocked_w) c0 = __builtin_readcyclecounter();
       if (s >= 1 && mrow < nrows) {
         const int64_t cell = first_cell + (s - 1) * wg_per_blk;
         const int row = row0 + mrow;
         const uint16_t *cl = cl_lds + mrow * (4 * NG);
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
 #if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 1))
+        // ranks >= 4 are the second merging wave of their SIMD (roles above: one merging wave per SIMD first)
         merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips,
-                            tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow, tl_top, tl_bot);
+                            tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow, tl_top, tl_bot,
+                            (n_merge > 4 && ROWS == kWholeRows) ? int(rank >= 4) : -1);
 #endif
       }
-      if (clocked) c1 = __builtin_readcyclecounter();
+      if (clocked || clocked_w) c1 = __builtin_readcyclecounter();
+      if (clocked_w) {
+        atomicAdd(&pd.clk[8 + rank], c1 - c0);
+        if (rank == 0) atomicAdd(&pd.clk[3], 1ull);
+        atomicAdd(&pd.clk[20 + rank], (unsigned long long)my_simd);
+      }
       __syncthreads();  // merge of block s - 1 done: image free
       if (clocked) c2 = __builtin_readcyclecounter();
       __syncthreads();  // image of block s ready
@@ -2212,10 +2239,10 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.debug = 0;
 #endif
   pd.clk = nullptr;
-  if (pd.debug & (8 | 32)) {
+  if (pd.debug & (8 | 32 | 1024)) {
     if (plan->clk.bytes == 0) {
-      HDP_HIP_TRY(plan->clk.alloc(8 * sizeof(unsigned long long)));
-      HDP_HIP_TRY(hipMemset(plan->clk.p, 0, 8 * sizeof(unsigned long long)));
+      HDP_HIP_TRY(plan->clk.alloc(32 * sizeof(unsigned long long)));
+      HDP_HIP_TRY(hipMemset(plan->clk.p, 0, 32 * sizeof(unsigned long long)));
     }
     pd.clk = plan->clk.as<unsigned long long>();
   }
@@ -2824,8 +2851,14 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
 
 extern "C" int hdp_threshold_plan_destroy(hdp_threshold_plan *plan) {
   if (plan && plan->clk.bytes) {  // HDP_THR_DEBUG=8: per-phase clocks of the lead wave, summed over blocks
-    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpy(c, plan->clk.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && c[3] && (c[4] | c[5]))
+    unsigned long long c[32] = {0};
+    if (hipMemcpy(c, plan->clk.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && c[3] && c[8]) {
+      fprintf(stderr, "[hdp thresholds lane] items=%llu  busy ticks/item by wave rank (mergers first, then producers):", c[3]);
+      for (int r = 0; r < 12; ++r) fprintf(stderr, " %.0f", double(c[8 + r]) / c[3]);
+      fprintf(stderr, "  | mean SIMD of merging ranks:");
+      for (int r = 0; r < 6; ++r) fprintf(stderr, " %.2f", double(c[20 + r]) / c[3]);
+      fprintf(stderr, "\n");
+    } else if (c[3] && (c[4] | c[5]))
       fprintf(stderr,
               "[hdp thresholds pipe] items=%llu  ticks/item: merge=%.0f wait_producers=%.0f wait_image=%.0f | "
               "producer: gather=%.0f sort=%.0f wait_merge=%.0f write=%.0f\n",
