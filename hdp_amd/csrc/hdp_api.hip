@@ -524,11 +524,20 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   pl->defs_host.assign(defs, defs + D * 3);
   // HDP_METRICS_* selectors: read here, once (tests and A/B runs; every value gives the same results)
   pl->opt_general = env_option("HDP_METRICS_GENERAL", 0) != 0;
+#ifdef HDP_CROSSCHECK_KERNELS
   pl->opt_fused = env_option("HDP_METRICS_FUSED", 0) != 0;
   pl->opt_cells = env_option("HDP_METRICS_CELLS", 1) != 0;
+#else  // the round-1 (percentile, definition)-per-lane kernels are cross-checks: `make EXTRA=-DHDP_CROSSCHECK_KERNELS`
+  pl->opt_fused = 0;
+  pl->opt_cells = 1;
+#endif
   pl->opt_packed = env_option("HDP_METRICS_PACKED", 1) != 0;
   pl->opt_overlap = env_option("HDP_METRICS_OVERLAP", 1) != 0;
+#ifdef HDP_CROSSCHECK_KERNELS
   pl->opt_pairs = env_option("HDP_METRICS_PAIRS", 1) != 0;
+#else
+  pl->opt_pairs = 1;
+#endif
   pl->opt_cw = (int32_t)env_option("HDP_METRICS_CW", 0);
   pl->opt_years = (int32_t)env_option("HDP_METRICS_YEARS", 1);   // 0: never, 1: records of >= 24 years, 2: any length
   pl->opt_years_lds = (int32_t)std::min<long long>(65536, std::max<long long>(0, env_option("HDP_METRICS_YEARS_LDS", 16384)));

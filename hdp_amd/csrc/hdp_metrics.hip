@@ -308,6 +308,7 @@ __device__ __forceinline__ void store32(int16_t *dst, const uint32_t (&a)[8]) {
 // latency by occupancy; the state-machine kernel that follows then needs no thresholds at all.
 // CW = 64-day words per wave and chunk (lane w of an accumulator holds word w): 32, or 16 for records of at most 64 words
 // (T <= 4096), where 32-word chunks would leave two of the four waves without work.
+#ifdef HDP_CROSSCHECK_KERNELS  // round-1 kernels kept as cross-checks: `make EXTRA=-DHDP_CROSSCHECK_KERNELS`
 template <int CW>
 __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__restrict__ x,
                                                      const double *__restrict__ thr, int64_t n_thr_cells,
@@ -388,6 +389,8 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
 // consecutive day-of-year rows fall on distinct bank pairs), and the lane's 32 LDS row addresses of a chunk sit in
 // registers and simply advance by 8 bytes per pass: 2 compares + 4 lane writes per word and pass, one add per word and
 // pass, i.e. 35 instead of 51 vector instructions per word at P = 10.  Same words, same scratch layout.
+#endif  // HDP_CROSSCHECK_KERNELS
+
 template <int CW>
 __global__ __launch_bounds__(256) void exceed_pairs_kernel(MetDev md, const float *__restrict__ x,
                                                            const double *__restrict__ thr, int64_t n_thr_cells,
@@ -561,6 +564,7 @@ __global__ __launch_bounds__(64) void exceed_years_kernel(MetDev md, const float
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
 }
 
+#ifdef HDP_CROSSCHECK_KERNELS
 template <bool SPLIT>
 __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
     MetDev md, const float *__restrict__ x, const double *__restrict__ thr, int64_t n_thr_cells,
@@ -797,6 +801,8 @@ __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
   while (si < Y) HDP_FINALIZE(false);
 #undef HDP_FINALIZE
 }
+#endif  // HDP_CROSSCHECK_KERNELS
+
 
 // ---- split path, kernel 2': lane = series, one wave = 64 series x one percentile x up to 6 definitions ----
 // The six definitions of a percentile see the same runs, so a lane extracts each run of its series once
@@ -2282,13 +2288,23 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   const bool short_record = ((md.T + 63) >> 6) <= 64 || plan->opt_cw == 16;  // at most two 32-word chunks: use 16-word chunks, all four waves
   if (split) {
     HDP_REQUIRE(lds_a <= kLdsPerCU - 1024, HDP_EUNSUP, "too many percentiles for the exceedance kernel");
+#ifdef HDP_CROSSCHECK_KERNELS
     const void *ek = pairs ? (short_record ? reinterpret_cast<const void *>(exceed_pairs_kernel<16>)
                                            : reinterpret_cast<const void *>(exceed_pairs_kernel<32>))
                            : (short_record ? reinterpret_cast<const void *>(exceed_kernel<16>)
                                            : reinterpret_cast<const void *>(exceed_kernel<32>));
+#else
+    const void *ek = short_record ? reinterpret_cast<const void *>(exceed_pairs_kernel<16>)
+                                  : reinterpret_cast<const void *>(exceed_pairs_kernel<32>);
+#endif
     HDP_HIP_TRY(hipFuncSetAttribute(ek, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
   }
+#ifdef HDP_CROSSCHECK_KERNELS
   auto kern_rows = split ? metrics_kernel_uniform<true> : (uniform ? metrics_kernel_uniform<false> : metrics_kernel_general);
+#else
+  auto kern_rows = metrics_kernel_general;  // the plan never asks for the (percentile, definition)-per-lane kernels in this build
+  HDP_REQUIRE(by_cells || !uniform, HDP_EUNSUP, "cross-check kernels are not in this build");
+#endif
   if (!by_cells)
     HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_rows),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2345,10 +2361,12 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
         hipLaunchKernelGGL(exceed_pairs_kernel<16>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
       else if (pairs)
         hipLaunchKernelGGL(exceed_pairs_kernel<32>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
+#ifdef HDP_CROSSCHECK_KERNELS
       else if (short_record)
         hipLaunchKernelGGL(exceed_kernel<16>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
       else
         hipLaunchKernelGGL(exceed_kernel<32>, dim3((unsigned)nc), dim3(256), lds_a, sx, mb, x_b, thr_b, ntc_b, nc);
+#endif
       HDP_HIP_TRY(hipGetLastError());
       if (overlap) {
         HDP_HIP_TRY(hipEventRecord(plan->ev_exceed[half], sx));
