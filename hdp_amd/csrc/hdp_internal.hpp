@@ -106,7 +106,6 @@ struct hdp_threshold_plan {
   // the merging waves work on the current one
   bool pipe = false;
   bool select_only = false;  // LDS sized without merge heads: only the rank-selection kernel can run this plan
-  bool lane_select = false;  // lane-per-column kernel, whole-cell form, with the rank selection instead of the merge
   int32_t lpc = 0;          // lanes per column of the register sort (1..16), 8 keys per lane
   int32_t n_merge = 0;      // waves that merge (ceil(rows_per_block / 64)); the rest produce
   hdp::DevBuf tix;          // int32 [block columns][8 * lpc] time index of sample e of a column, -1 = none

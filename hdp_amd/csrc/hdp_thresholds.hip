@@ -53,7 +53,6 @@ struct ThrDev {
   const int32_t *blk_grp_off, *grp_col;  // 16-byte gathers: first column of every group of four, per block
   int SL, n_merge;                             // pitch of tix (8 * lanes per column); merging waves
   int select;                                  // one-workgroup-per-cell kernel: rank selection instead of the merge
-  int lane_select;                             // lane-per-column kernel (whole-cell form): the same selection on its image
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
   // Timing ablations and instrumentation: compiled in only with -DHDP_DEBUG_ABLATIONS (a release build ignores
@@ -1043,12 +1042,10 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
 // The adjacent pair (R, R + 1) is exactly what one interpolated quantile needs.
 template <int NC>
 __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, const uint32_t *flags, int row0,
-                                            int nrows, int tid, int64_t cell, double *__restrict__ out,
-                                            int col_pitch = 0, int n_threads = kThrThreads) {
+                                            int nrows, int tid, int64_t cell, double *__restrict__ out) {
   const int nt_all = pd.nt_top + pd.nt_bot;
   const int S = pd.S, W = pd.W;
-  if (col_pitch == 0) col_pitch = pd.S_pad;  // words per LDS column (sentinel, S keys, sentinel, padding)
-  for (int task = tid; task < nrows * nt_all; task += n_threads) {
+  for (int task = tid; task < nrows * nt_all; task += kThrThreads) {
     const int r = task % nrows, ti = task / nrows;
     const bool top = ti < pd.nt_top;
     const int2 t = top ? pd.tgt_top[ti] : pd.tgt_bot[ti - pd.nt_top];
@@ -1069,7 +1066,7 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
       nan_or |= f;
       rf.n_pos += (f >> 15) & 0x7fff;
       rf.n_neg += f & 0x7fff;
-      base[j] = c * col_pitch;
+      base[j] = c * pd.S_pad;
       lo[j] = 0;
       hi[j] = (j < W) ? min(S, R) : 0;  // no column holds more than the R keys ranked above the wanted one
     }
@@ -1657,14 +1654,9 @@ constexpr int lane_tasks_per_wave() { return N >= 64 ? 1 : (N >= 32 ? 2 : 4); }
 // ROWS = strip pitch: kLeanRows (blocks of <= 128 rows, up to 8 waves, two or three workgroups per CU) or kWholeRows (every
 // day-of-year row of a cell in one 12-wave workgroup per CU: no halo columns -- each column is sorted once per cell --
 // and all 365 merge chains of the cell in flight at once)
-// SELECT (whole-cell form, untiered): the merging waves run the rank selection of select_rows -- one lane per (row,
-// requested rank) -- instead of the W-way merge, on an image of order-preserving int keys.  The merge walks down to
-// the deepest requested rank (151 steps for q >= 0.90 of 1500 samples, 750 for a median); the selection costs the
-// same whatever the ranks, so the plan takes it when the walk is long (quantile sets away from the tails).
-template <int N, int NG, bool TIER, int ROWS, bool SELECT = false>
+template <int N, int NG, bool TIER, int ROWS>
 __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, HDP_WHOLE_MINW) void thresholds_lane_kernel(ThrDev pd, const float *__restrict__ x,
                                                                       int64_t n_cells, double *__restrict__ out) {
-  static_assert(!SELECT || (!TIER && ROWS == kWholeRows), "the selection runs on whole, untiered columns");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1679,9 +1671,8 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
   off += 2 * size_t(flags_pitch) * 4;
   unsigned char *strips = smem + off;  // merge heads: 2nd..4th of every (group, row), see merge_row_lean
-  if (!SELECT) off += lean_strip_bytes<NG, ROWS>();
+  off += lean_strip_bytes<NG, ROWS>();
   uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][4 * NG] local columns of this block's windows (slots past W: the pseudo column)
-  (void)strips;
 
   const int nb = pd.n_blocks;
   const int blk = int(blockIdx.x) % nb;
@@ -1697,7 +1688,7 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   // this workgroup's global tail (tiered image), double-buffered by item parity like the census words
   const size_t tail_half = size_t(max(pd.S - pd.tier_k, 0) + 1) * pd.tail_pitch;
   float *const tail_wg = pd.tail + size_t(blockIdx.x) * 2 * tail_half;
-  for (int i = tid; !SELECT && i < nrows * 4 * NG; i += int(blockDim.x)) {  // (the selection reads the lists from L2)
+  for (int i = tid; i < nrows * 4 * NG; i += int(blockDim.x)) {
     const int r = i / (4 * NG), j = i % (4 * NG);
     cl_lds[i] = (j < pd.W) ? pd.cols_local[size_t(row0 + r) * pd.W + j] : uint16_t(pd.ncols_max);
   }
@@ -1829,14 +1820,12 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
             if constexpr (!TIER) {  // whole column in LDS
 #pragma unroll
               for (int i = 0; i < N; ++i) {
-                // the selection compares integers: order-preserving keys instead of the raw float bits
-                const int w = SELECT ? f32_key(__int_as_float(v[k][i])) : v[k][i];
                 // slots below the first possible padding slot always hold a sample: constant LDS offsets (a run-time
                 // min() on every slot gave N loop-invariant addresses, hoisted into N registers)
-                if (i < lane_first_pad_slot(N)) col[i] = __int_as_float(w);
-                else col[min(i, S_rt)] = __int_as_float(w);
+                if (i < lane_first_pad_slot(N)) col[i] = __int_as_float(v[k][i]);
+                else col[min(i, S_rt)] = __int_as_float(v[k][i]);
               }
-              col[S_rt] = SELECT ? __int_as_float(kKeyMin) : __uint_as_float(kRawMin);  // loses every descending walk
+              col[S_rt] = __uint_as_float(kRawMin);  // loses every descending walk
             } else {
               // tiered: the top kTierK samples to LDS, the marker behind them, the rest to the workgroup's global tail
               // [sample - kTierK][column] (a store instruction writes 64 adjacent columns); slots past S land on a
@@ -1860,7 +1849,7 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
               col[kTierK + 1] = __uint_as_float(kRawMin);  // what the heads of window slots past W read
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail stores are asm: the barrier's own wait does not count them
             }
-            col[-1] = SELECT ? __int_as_float(kKeyMax) : __uint_as_float(kRawMax);  // loses every ascending walk
+            col[-1] = __uint_as_float(kRawMax);    // loses every ascending walk
           }
         }
       }
@@ -1881,14 +1870,6 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
       const bool clocked = HDP_DBG(pd, 32) && lane == 0 && rank == 0;
       const bool clocked_w = HDP_DBG(pd, 1024) && lane == 0;
       if (clocked || clocked_w) c0 = __builtin_readcyclecounter();
-      if constexpr (SELECT) {
-        if (s >= 1) {  // every lane of the merging waves takes (row, rank) tasks of the cell
-          const int64_t cell = first_cell + (s - 1) * wg_per_blk;
-          const int *colk = reinterpret_cast<const int *>(colbuf);
-          if (pd.W == 15) select_rows<15>(pd, colk, flags_m, row0, nrows, rank * 64 + lane, cell, out, pd.img_pitch, n_merge * 64);
-          else select_rows<16>(pd, colk, flags_m, row0, nrows, rank * 64 + lane, cell, out, pd.img_pitch, n_merge * 64);
-        }
-      } else
       if (s >= 1 && mrow < nrows) {
         const int64_t cell = first_cell + (s - 1) * wg_per_blk;
         const int row = row0 + mrow;
@@ -2101,10 +2082,6 @@ static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t
   const int n_tasks = (pd.ncols_max + 63) / 64;
   const bool whole = pd.n_blocks == 1 && pd.RP > kLeanRows;  // the plan put every row of a cell into one workgroup
   const int threads = std::min<int>(whole ? kWholeThreads : kThrThreads, 64 * (pd.n_merge + (n_tasks + tpw - 1) / tpw));
-  if (pd.lane_select) {
-    HDP_REQUIRE(whole && pd.tier_k >= pd.S && pd.W <= 16, HDP_EUNSUP, "lane-per-column selection: not a whole-cell, untiered plan");
-    return launch_thr_persistent(thresholds_lane_kernel<N, 4, false, kWholeRows, true>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
-  }
   switch (pd.Wp >> 2) {
     case 1:
       if constexpr (N > 64) {
@@ -2192,8 +2169,7 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
              plan->lane_n, plan->Wp >> 2,
              plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : (plan->n_blocks == 1 && plan->RP > hdp::kLeanRows ? ",whole-cell" : ""), plan->n_merge,
              plan->rows_per_block, plan->n_blocks, plan->lane_lds_bytes,
-             plan->lane_select ? "; rank selection per (row, rank) instead of the merge"
-                               : (plan->lane_tier_k < plan->S ? "; top 60 samples of a column in LDS, the rest in a global tail" : ""));
+             plan->lane_tier_k < plan->S ? "; top 60 samples of a column in LDS, the rest in a global tail" : "");
   else if (v.pipe)
     snprintf(buf, sizeof buf,
              "thresholds_pipe_kernel<LPC=%d,%s,NG=%d> (register sort producers + %d merging waves; %d rows x %d blocks, "
@@ -2253,7 +2229,6 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.tixl = plan->tixl.as<int32_t>();
   pd.blk_tixl_off = plan->blk_tixl_off.as<int32_t>();
   pd.tier_k = plan->lane_tier_k;
-  pd.lane_select = plan->lane_select ? 1 : 0;
   pd.img_pitch = plan->lane_img_pitch;
   pd.tail_pitch = ((plan->ncols_max + 63) / 64) * 64;
   pd.tail = nullptr;
@@ -2543,31 +2518,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
       }
     }
   }
-  // Whole-cell form with the rank SELECTION instead of the merge: whole columns (any S <= 100) as int keys, no merge
-  // heads and no window lists in LDS.  The merge costs ~41 instructions per step and row, the selection ~1200 per (row,
-  // requested quantile) whatever the ranks: taken when the walk is long (quantile sets away from the tails; C3 with ten
-  // quantiles around the median: 61 -> 15 ms per 65 536 cells).  HDP_THR_SELECT=1 / 0 forces / forbids it.
-  {
-    const int nt_all = pl->nt_top + pl->nt_bot;
-    const bool long_walk = int64_t(pl->steps_top + pl->steps_bot) * 41 > int64_t(nt_all) * 1200;
-    const bool want = pl->opt_select > 0 || (pl->opt_select < 0 && long_walk);
-    const bool cand = want && S >= 3 && S <= 100 && W <= 16 && hdp::lane_slots_for(S) > 0 && pl->opt_lane != 0 &&
-                      pl->opt_pipe != 0 && opt_rows <= 0 && hdp::env_option("HDP_THR_WHOLE", 1) != 0 &&
-                      n_doy <= hdp::kWholeRows && T < (int64_t(1) << 29);
-    if (cand) {
-      size_t b = (size_t(n_doy + 1) * spad * 4 + 15) & ~size_t(15);
-      b += 2 * ((size_t(n_doy) * 4 + 15) & ~size_t(15));
-      b += 64;
-      const int n_slots = hdp::lane_slots_for(S);
-      const int nm = int((n_doy + 63) / 64);
-      const int waves = nm + (nm + hdp::lane_tasks_per_wave_rt(n_slots) - 1) / hdp::lane_tasks_per_wave_rt(n_slots);
-      if (b <= kMaxLds && waves * 64 <= hdp::kWholeThreads) {
-        whole = true;
-        whole_lds = b;
-        pl->lane_select = true;
-      }
-    }
-  }
   int rows = whole ? (int)n_doy : opt_rows;
   if (rows <= 0) {
     // largest row count whose worst block fits `cap` bytes of LDS
@@ -2646,7 +2596,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     // draws more than that from one column) and the rest in a global tail: three workgroups per CU instead of two.
     // (only the whole-cell form gains from it: three 5-wave workgroups of the blocked form do not fit a CU's
     // register file side by side, measured)
-    pl->lane_tier_k = (whole && S > 64 && !pl->lane_select) ? hdp::kTierK : (int32_t)S;
+    pl->lane_tier_k = (whole && S > 64) ? hdp::kTierK : (int32_t)S;
     int ip = pl->lane_tier_k < S ? pl->lane_tier_k + 3 : spad;  // sentinel, samples, marker, sentinel
     if ((ip & 1) == 0) ++ip;
     pl->lane_img_pitch = ip;

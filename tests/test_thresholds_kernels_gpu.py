@@ -84,11 +84,6 @@ def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
     assert same_f64(run(HDP_THR_LANE="0", HDP_THR_VEC="0"), want)   # pipelined kernel, one dword per (column, sample)
     assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="0"), want)   # one workgroup per cell, merge
     assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="1"), want)   # same, rank selection per (row, rank)
-    # lane-per-column kernel, whole-cell form, with the selection in place of the merge (plans of <= 100 samples per
-    # column and <= 16 window columns; elsewhere the switch changes nothing) -- and with the merge where a long walk
-    # would have made the plan choose the selection by itself
-    assert same_f64(run(HDP_THR_SELECT="1"), want)
-    assert same_f64(run(HDP_THR_SELECT="0"), want)
 
 
 def test_tiered_image_deep_columns_reach_the_global_tail():
@@ -162,29 +157,9 @@ def test_random_calendars_windows_and_quantiles(seed, monkeypatch):
     with np.errstate(invalid="ignore"):
         want = c_oracle.thresholds(x, win, q)
     for env in ({}, {"HDP_THR_WHOLE": "0"}, {"HDP_THR_LANE": "0"}, {"HDP_THR_LANE": "0", "HDP_THR_VEC": "0"},
-                {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "0"}, {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "1"},
-                {"HDP_THR_SELECT": "1"}, {"HDP_THR_SELECT": "0"}):
+                {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "0"}, {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "1"}):
         for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE", "HDP_THR_WHOLE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         assert same_f64(core.compute_percentiles(x, ti, cols, q), want), (env, years, radius, q)
-
-
-def test_long_walks_take_the_selection_in_the_lane_kernel(monkeypatch):
-    """C3's calendar (100 years, radius 7): the tail set keeps the merge (151 steps), ten quantiles around the median
-    (a 750-step walk) and a spread set make the plan choose the whole-cell selection; all of them match the oracle."""
-    for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE", "HDP_THR_WHOLE"):
-        monkeypatch.delenv(k, raising=False)
-    rng = np.random.default_rng(5)
-    dates = orc.noleap_date_range("0001-01-01", "0100-12-31")
-    T = dates.size
-    x = (20 + 2 * np.sin(2 * np.pi * np.arange(T) / 365.0)[None, :] + 0.7 * rng.random((6, T))).astype(np.float32)
-    x[5] = np.round(x[5], 1)
-    ti, cols = cal.window_columns(dates, 7)
-    win = cal.expand_window_table(ti, cols)
-    for q, sel in ((np.arange(0.9, 1.0, 0.01), False), (np.linspace(0.455, 0.545, 10), True),
-                   (np.linspace(0.05, 0.95, 10), True), ([0.0, 0.5, 1.0], True)):
-        plan = core.ThresholdPlan(ti, cols, q, T)
-        assert ("rank selection" in plan.describe()) == sel, plan.describe()
-        assert same_f64(core.compute_percentiles(x, ti, cols, q), c_oracle.thresholds(x, win, q))
