@@ -1007,222 +1007,6 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
   }
 }
 
-// ---- two rows per lane (HDP_MERGE_RPL == 2, whole-cell form) -------------------------------------------------------
-// A merging wave alone on its SIMD needs ~387 cycles per step: ~190 of issue (41 instructions at the single-wave rate of
-// one per ~4.6 cycles) and ~200 of latency it cannot cover (the LDS round trip and the dependent v_max/min_f64 chain
-// behind it).  With TWO rows per lane the second row's 41 instructions fill the first row's stalls: three merging waves
-// (one per SIMD, none sharing) carry the 365 rows that six carried, and no chain waits for another wave's issue slots.
-// Same arithmetic per row as merge_row_lean; the state is a struct so that the two rows' steps can be interleaved by hand:
-// pre (winner of the popped group, next winner) of A and B, the next step's LDS reads of A and B, then the insertions.
-template <bool TOP, int NG, bool TIER, int ROWS>
-struct LeanChain {
-  unsigned char *sA, *sB;
-  double m[NG];
-  double prev;
-  uint32_t nk, lo_cur, g_cur, g_prev;
-  double2 h12;
-  double h3;
-  double b1, b2, b3;
-  // carried from pre() to post()
-  double fresh, h1, t0, h2, h3v;
-  uint32_t g;
-  static __device__ __forceinline__ double better(double a, double b) { return TOP ? pk_max(a, b) : pk_min(a, b); }
-  static __device__ __forceinline__ double worse(double a, double b) { return TOP ? pk_min(a, b) : pk_max(a, b); }
-  static __device__ __forceinline__ double head(uint32_t bits, uint32_t pay) { return __hiloint2double(int(bits), int(pay)); }
-  __device__ __forceinline__ void issue(double top) {
-    lo_cur = uint32_t(__double2loint(top));
-    g_cur = lo_cur & 3u;
-    nk = lds_u32((lo_cur & 0x3fffcu) + (TOP ? 4u : uint32_t(-4)));
-    h12 = *reinterpret_cast<const double2 *>(sA + g_cur * (ROWS * 16));
-    h3 = *reinterpret_cast<const double *>(sB + g_cur * (ROWS * 8));
-  }
-  __device__ __forceinline__ void init(const ThrDev &pd, const unsigned char *image, unsigned char *strips, const uint16_t *cl,
-                                       int slot) {
-    sA = strips + size_t(slot) * 16;
-    sB = strips + size_t(NG) * ROWS * 16 + size_t(slot) * 8;
-    uint32_t pos[4 * NG];
-    const uint32_t img0 = uint32_t(reinterpret_cast<uintptr_t>(image));
-    const uint4 *cl4 = reinterpret_cast<const uint4 *>(cl);
-#pragma unroll
-    for (int v4 = 0; v4 < NG / 2 + (NG & 1); ++v4) {
-      uint32_t wv[4];
-      if (NG == 1) {
-        const uint2 h = *reinterpret_cast<const uint2 *>(cl);
-        wv[0] = h.x; wv[1] = h.y; wv[2] = wv[3] = 0;
-      } else {
-        const uint4 q4 = cl4[v4];
-        wv[0] = q4.x; wv[1] = q4.y; wv[2] = q4.z; wv[3] = q4.w;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j0 = v4 * 8 + 2 * u;
-        if (j0 < 4 * NG) pos[j0] = img0 + uint32_t(int(wv[u] & 0xffffu) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
-        if (j0 + 1 < 4 * NG) pos[j0 + 1] = img0 + uint32_t(int(wv[u] >> 16) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
-      }
-    }
-    uint32_t kb[4 * NG];
-#pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) kb[j] = lds_u32(pos[j]);
-#pragma unroll
-    for (int gq = 0; gq < NG; ++gq) {
-      double hd[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) hd[i] = head(kb[4 * gq + i], pos[4 * gq + i] | uint32_t(gq));
-      sort_best_first<TOP, 4>(hd);
-      *reinterpret_cast<double2 *>(sA + gq * (ROWS * 16)) = make_double2(hd[1], hd[2]);
-      *reinterpret_cast<double *>(sB + gq * (ROWS * 8)) = hd[3];
-      m[gq] = hd[0];
-    }
-    sort_best_first<TOP, NG>(m);
-    prev = head(TOP ? kRawMin : kRawMax, 0);
-    b1 = b2 = b3 = 0.0;
-    g_prev = 4;
-    issue(m[0]);
-  }
-  // the popped group's new top and the row's next winner (returns it: the caller issues its reads).  Split in three so
-  // that the two rows of a lane share ONE wave-level branch for the (rare) tiered-image tail fetch and everything else is
-  // straight-line code the scheduler can interleave between the rows.
-  uint32_t pay;
-  __device__ __forceinline__ bool pre_mark() {
-    prev = m[0];
-    g = g_cur;
-    pay = lo_cur + (TOP ? 4u : uint32_t(-4));
-    return (TOP && TIER) ? int(nk) >= int(0x7ff00000u) : false;
-  }
-  __device__ __forceinline__ void pre_tail(const ThrDev &pd, const float *tail_cur, bool mk) {
-    if constexpr (TOP && TIER) {
-      const uint32_t c = nk & 0xfffffu;
-      const uint32_t p1n = (lo_cur & 0x40000000u) ? ((lo_cur >> 18) & 0x7ffu) + 1u : uint32_t(pd.tier_k) + 1u;
-      uint32_t v = kRawMin;
-      if (mk && p1n <= uint32_t(pd.S)) {
-        const uint32_t off = ((p1n - uint32_t(pd.tier_k) - 1u) * uint32_t(pd.tail_pitch) + c) * 4u;
-        asm volatile("global_load_dword %0, %1, %2 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(off), "s"(tail_cur) : "memory");
-      }
-      if (mk) {
-        nk = v;
-        pay = 0x40000000u | (p1n << 18) | (lo_cur & 0x3ffffu);
-      }
-    }
-  }
-  // the step in pieces of one or two instructions each: the caller alternates the two rows of a lane piece by piece
-  // (scheduling barriers between the pieces), so that every dependent v_max/min_f64 of one row issues behind an
-  // independent one of the other -- a wave issues in order, and left to the compiler each row's chain came out whole
-  // (22.0 ms per 131 072 cells against 14.5 with one row per lane)
-  double w, w1, w2, m0n;
-  __device__ __forceinline__ void f1() {
-    const bool same = g == g_prev;
-    fresh = head(nk, pay);
-    h1 = same ? b1 : h12.x;
-    h2 = same ? b2 : h12.y;
-    h3v = same ? b3 : h3;
-  }
-  __device__ __forceinline__ void f2() { t0 = better(fresh, h1); }
-  __device__ __forceinline__ void f3() {
-    m0n = t0;
-    if constexpr (NG >= 2) m0n = better(t0, m[1]);
-  }
-  __device__ __forceinline__ void q1() {
-    w1 = worse(fresh, h1);
-    if constexpr (NG >= 2) w = worse(t0, m[1]);
-  }
-  __device__ __forceinline__ void q2() {
-    b1 = better(w1, h2);
-    w2 = worse(w1, h2);
-  }
-  __device__ __forceinline__ void q3() {
-    b2 = better(w2, h3v);
-    b3 = worse(w2, h3v);
-  }
-  __device__ __forceinline__ void q4() {
-    *reinterpret_cast<double2 *>(sA + g * (ROWS * 16)) = make_double2(b1, b2);
-    *reinterpret_cast<double *>(sB + g * (ROWS * 8)) = b3;
-    g_prev = g;
-    m[0] = m0n;
-  }
-  template <int I>
-  __device__ __forceinline__ void q5() {  // stage I of the cached tops' insertion (I = 1 .. NG - 1)
-    if constexpr (NG >= 2 && I + 1 < NG) {
-      const double nb = better(w, m[I + 1]);
-      w = worse(w, m[I + 1]);
-      m[I] = nb;
-    } else if constexpr (NG >= 2 && I + 1 == NG) {
-      m[NG - 1] = w;
-    }
-  }
-};
-
-template <bool TOP, int NG, bool TIER, int ROWS>
-__device__ __forceinline__ void merge_row_lean2(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
-                                                const float *tail_cur, const uint16_t *clA, const uint16_t *clB, int slotA,
-                                                int slotB, const RowFlags &rfA, const RowFlags &rfB, double *orowA,
-                                                double *orowB, const TgtLanes &tl) {
-  const int steps = TOP ? pd.steps_top : pd.steps_bot;
-  const int nt = TOP ? pd.nt_top : pd.nt_bot;
-  if (steps == 0) return;
-  LeanChain<TOP, NG, TIER, ROWS> A, B;
-  A.init(pd, image, strips, clA, slotA);
-  B.init(pd, image, strips, clB, slotB);
-  int k = 0;
-  int next_rank = nt > 0 ? __builtin_amdgcn_readlane(tl.rank, 0) : -1;
-  int step = 0;
-  while (true) {
-    const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
-    for (; step < stop; ++step) {
-      const bool mkA = A.pre_mark(), mkB = B.pre_mark();
-      if (TOP && TIER && __ballot(mkA || mkB) != 0) {  // rare: some lane's next sample lives in the global tail
-        A.pre_tail(pd, tail_cur, mkA);
-        B.pre_tail(pd, tail_cur, mkB);
-      }
-#define HDP_BOTH(piece)                   \
-  A.piece;                                \
-  B.piece;                                \
-  __builtin_amdgcn_sched_barrier(0)
-      HDP_BOTH(f1());
-      HDP_BOTH(f2());
-      HDP_BOTH(f3());
-      A.issue(A.m0n);  // both rows' next reads in flight before either insertion
-      B.issue(B.m0n);
-      __builtin_amdgcn_sched_barrier(0);
-      HDP_BOTH(q1());
-      HDP_BOTH(q2());
-      HDP_BOTH(q3());
-      HDP_BOTH(q4());
-      HDP_BOTH(template q5<1>());
-      HDP_BOTH(template q5<2>());
-      HDP_BOTH(template q5<3>());
-#undef HDP_BOTH
-    }
-    if (step >= steps) break;
-    int kA = k, nrA = next_rank;
-    emit_targets_lanes<TOP>(pd, tl, nt, kA, nrA, step, __double2hiint(A.m[0]), __double2hiint(A.prev), rfA, orowA);
-    emit_targets_lanes<TOP>(pd, tl, nt, k, next_rank, step, __double2hiint(B.m[0]), __double2hiint(B.prev), rfB, orowB);
-    next_rank = __builtin_amdgcn_readfirstlane(next_rank);
-  }
-}
-
-template <int NG, bool TIER, int ROWS>
-__device__ __forceinline__ void merge_both_lean2(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
-                                                 const float *tail_cur, const uint32_t *flags, const uint16_t *clA,
-                                                 const uint16_t *clB, int slotA, int slotB, double *orowA, double *orowB,
-                                                 const TgtLanes &tl_top, const TgtLanes &tl_bot) {
-  RowFlags rf[2] = {{0, 0}, {0, 0}};
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint16_t *cl = h ? clB : clA;
-    uint32_t nan_or = 0;
-#pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) {
-      const uint32_t f = (j < pd.W) ? flags[cl[j]] : 0u;
-      nan_or |= f;
-      rf[h].n_pos += (f >> 15) & 0x7fff;
-      rf[h].n_neg += f & 0x7fff;
-    }
-    if (nan_or >> 31) rf[h].n_pos = -1;
-  }
-  merge_row_lean2<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, clA, clB, slotA, slotB, rf[0], rf[1], orowA, orowB, tl_top);
-  merge_row_lean2<false, NG, false, ROWS>(pd, image, strips, tail_cur, clA, clB, slotA, slotB, rf[0], rf[1], orowA, orowB, tl_bot);
-}
-
 template <int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
                                                 const float *tail_cur, const uint32_t *flags, const uint16_t *cl, int r,
@@ -2086,21 +1870,6 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
       const bool clocked = HDP_DBG(pd, 32) && lane == 0 && rank == 0;
       const bool clocked_w = HDP_DBG(pd, 1024) && lane == 0;
       if (clocked || clocked_w) c0 = __builtin_readcyclecounter();
-#if defined(HDP_MERGE_RPL) && HDP_MERGE_RPL == 2
-      if (ROWS == kWholeRows && tl_top.ok && tl_bot.ok) {
-        if (s >= 1 && mrow < nrows) {
-          // rows mrow and mrow + 64 * n_merge of the cell on this lane; a lane without a second row repeats its first
-          // one into a spare strip slot (the strips have ROWS = 384 slots)
-          const int64_t cell = first_cell + (s - 1) * wg_per_blk;
-          const int rB0 = mrow + 64 * n_merge;
-          const int rB = rB0 < nrows ? rB0 : mrow;
-          double *ocell = out + cell * pd.n_doy * int64_t(pd.P) + row0;
-          merge_both_lean2<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips,
-                                           tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl_lds + mrow * (4 * NG),
-                                           cl_lds + rB * (4 * NG), mrow, rB0, ocell + mrow, ocell + rB, tl_top, tl_bot);
-        }
-      } else
-#endif
       if (s >= 1 && mrow < nrows) {
         const int64_t cell = first_cell + (s - 1) * wg_per_blk;
         const int row = row0 + mrow;
@@ -2854,10 +2623,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   pl->pipe = pipe;
   pl->lpc = lpc;
   pl->n_merge = (rows + 63) / 64;
-#if defined(HDP_MERGE_RPL) && HDP_MERGE_RPL == 2
-  // whole-cell lane kernel: two rows per lane, half the merging waves (emission tables across lanes: <= 64 targets)
-  if (whole && lane && pl->nt_top <= 64 && pl->nt_bot <= 64) pl->n_merge = (rows + 127) / 128;
-#endif
   pl->rows_per_block = rows;
   pl->RP = (rows + 63) & ~63;
   pl->ncols_max = cm;
