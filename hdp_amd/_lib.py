@@ -48,6 +48,7 @@ SIGNATURES = {
     "hdp_event_destroy": (C.c_int, [vp]),
     "hdp_threshold_plan_create": (C.c_int, [vp, i64, i64, vp, i64, vp, i64, i64, P(vp)]),
     "hdp_threshold_plan_destroy": (C.c_int, [vp]),
+    "hdp_threshold_plan_reserve": (C.c_int, [vp, i64, C.c_int]),
     "hdp_threshold_plan_describe": (C.c_char_p, [vp]),
     "hdp_thresholds_f32_dev": (C.c_int, [vp, vp, i64, vp, vp]),
     "hdp_thresholds_f32": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, vp, i64, vp, i64, vp]),

@@ -294,6 +294,10 @@ class ThresholdPlan:
                                                       _ptr(q), self.P, self.T, C.byref(h)))
         self.handle = h
 
+    def reserve(self, n_cells, time_major=False):
+        """Allocate the plan's launch-time scratch up front (keeps run() free of synchronisation and hipMalloc)."""
+        _lib.check(self.lib.hdp_threshold_plan_reserve(self.handle, int(n_cells), int(bool(time_major))))
+
     def run(self, x_ptr, n_cells, out_ptr, stream=None):
         """Device pointers; out is [n_cells][P][n_doy] float64 (percentile-major, what MetricsPlan.run reads)."""
         _lib.check(self.lib.hdp_thresholds_f32_dev(self.handle, x_ptr, int(n_cells), out_ptr, stream))

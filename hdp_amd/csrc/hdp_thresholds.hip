@@ -2039,6 +2039,9 @@ static int launch_thr_pipe(const ThrDev &pd, size_t lds, const float *x, int64_t
 
 // persistent grid shared by the pipelined and the lane-per-column kernel: as many workgroups as the device keeps
 // resident, a multiple of n_blocks (workgroup w works on block w % n_blocks for cells w / n_blocks + k * (grid / n_blocks))
+// hdp_threshold_plan_reserve: walk the launch path, allocate what a launch of that size would, launch nothing
+static thread_local bool g_reserve_only = false;
+
 template <class Kern>
 static int launch_thr_persistent(Kern kern, const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
                                  int64_t grid_override, int threads, hipStream_t stream, DevBuf *tail_buf = nullptr) {
@@ -2068,6 +2071,7 @@ static int launch_thr_persistent(Kern kern, const ThrDev &pd, size_t lds, const 
     }
     pdl.tail = tail_buf->as<float>();
   }
+  if (g_reserve_only) return HDP_OK;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, stream, pdl, x, n_cells, out);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
@@ -2315,6 +2319,10 @@ int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, 
     const hipError_t e = plan->tm_stage.alloc(need);
     if (e != hipSuccess)
       return set_error(HDP_ENOMEM, "allocating %zu bytes of time-major staging failed: %s", need, hipGetErrorString(e));
+  }
+  if (g_reserve_only) {  // staging, stream and events exist now; the tiered image's tail for one chunk (nothing launches)
+    if (plan->lane && plan->lane_tier_k < plan->S) return launch_thresholds(plan, plan->tm_stage.as<float>(), chunk, out_dev, stream);
+    return HDP_OK;
   }
   HDP_HIP_TRY(hipEventRecord(plan->tm_fork, stream));
   HDP_HIP_TRY(hipStreamWaitEvent(plan->tm_stream, plan->tm_fork, 0));
@@ -2847,6 +2855,21 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   }
   *plan_out = pl;
   return HDP_OK;
+}
+
+extern "C" int hdp_threshold_plan_reserve(hdp_threshold_plan *plan, int64_t n_cells, int time_major) {
+  HDP_REQUIRE(hdp::device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(plan && n_cells >= 0, HDP_EINVAL, "bad arguments");
+  if (n_cells == 0) return HDP_OK;
+  // only the lane-per-column kernel's tiered image and the time-major path own scratch; the other kernels allocate nothing
+  hdp::g_reserve_only = true;
+  double *const no_out = reinterpret_cast<double *>(uintptr_t(16));   // never dereferenced: nothing is launched
+  const float *const no_x = reinterpret_cast<const float *>(uintptr_t(16));
+  int rc = HDP_OK;
+  if (time_major) rc = hdp::launch_thresholds_tm(plan, no_x, n_cells, n_cells, no_out, hdp::default_stream());
+  else if (plan->lane && plan->lane_tier_k < plan->S) rc = hdp::launch_thresholds(plan, no_x, n_cells, no_out, hdp::default_stream());
+  hdp::g_reserve_only = false;
+  return rc;
 }
 
 extern "C" int hdp_threshold_plan_destroy(hdp_threshold_plan *plan) {

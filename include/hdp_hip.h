@@ -91,6 +91,10 @@ int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_doy, int64_t 
                               const double *q, int64_t P, int64_t T,
                               hdp_threshold_plan **plan_out);
 int hdp_threshold_plan_destroy(hdp_threshold_plan *plan);
+/* Allocate up front whatever scratch a launch of up to n_cells cells would allocate on first use (the tiered image's
+ * global tail; with time_major != 0 also the staging buffers, copy stream and events of hdp_thresholds_f32_tm_dev), so
+ * that later launches neither synchronise nor call hipMalloc.  Needs hdp_init. */
+int hdp_threshold_plan_reserve(hdp_threshold_plan *plan, int64_t n_cells, int time_major);
 /* Human-readable name and shape of the kernel a launch of this plan runs (the HDP_THR_* environment switches are
  * read ONCE, when the plan is created, never at launch); thread-local storage, valid until the next call.
  *

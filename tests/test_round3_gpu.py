@@ -217,3 +217,33 @@ def test_queued_state_machines_random_sweep(seed, monkeypatch):
             pytest.skip("prototype kernel not in this build (make EXTRA=-DHDP_PROTO_QUEUE)")
         got = core.compute_heatwave_metrics(*case)
         assert np.array_equal(got.astype(np.int64), want), (cap, n_doy, T, P, defs)
+
+
+def test_threshold_plan_reserve_then_launch():
+    """hdp_threshold_plan_reserve: the tiered image's tail (and, time-major, the staging) exist before the first launch; the
+    launches that follow give the results of a plan that allocated on first use."""
+    import torch
+    dev = torch.device("cuda", 0)
+    lib = _lib.ensure_device()
+    dates = utils.noleap_date_range("2000-01-01", "2099-12-31")
+    ti, cols = cal.window_columns(dates, 7)
+    q = np.arange(0.9, 1.0, 0.01)
+    T, n = dates.size, 700
+    lat = torch.linspace(-60, 60, n, device=dev)
+    x = torch.empty(n * T, dtype=torch.float32, device=dev)
+    _lib.check(lib.hdp_generate_series_dev(x.data_ptr(), n, T, 3, lat.data_ptr(), 5, 0.7, 0.0, None))
+    a = core.ThresholdPlan(ti, cols, q, T)
+    b = core.ThresholdPlan(ti, cols, q, T)
+    b.reserve(n)
+    b.reserve(n, time_major=True)
+    out_a = torch.empty(n * q.size * 365, dtype=torch.float64, device=dev)
+    out_b = torch.empty_like(out_a)
+    out_c = torch.empty_like(out_a)
+    a.run(x.data_ptr(), n, out_a.data_ptr())
+    b.run(x.data_ptr(), n, out_b.data_ptr())
+    xt = x.view(n, T).t().contiguous()
+    b.run_time_major(xt.data_ptr(), n, n, out_c.data_ptr())
+    torch.cuda.synchronize(dev)
+    _lib.check(lib.hdp_sync(None))
+    assert bool(torch.equal(out_a.view(torch.int64), out_b.view(torch.int64)))
+    assert bool(torch.equal(out_a.view(torch.int64), out_c.view(torch.int64)))
