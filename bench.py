@@ -442,7 +442,7 @@ def main():
         dist.destroy_process_group()
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, script=None, argv=None):
     """Start `n` fresh rank processes of this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as a
     launcher would) and wait for them.  Rank 0 inherits stdout, so its JSON line is this command's line; the return
     value is the worst exit code of the ranks (a rank killed by a signal counts as 128 + signal)."""
@@ -459,7 +459,8 @@ def spawn_ranks(n):
                    MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "1" if r else str(os.cpu_count() or 1))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)]
+                                      + list(sys.argv[1:] if argv is None else argv), env=env))
     worst = 0
     try:
         for pr in procs:
