@@ -2412,6 +2412,8 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   struct Tgt { int rank, slot; };  // slot = quantile index | EmitKind << 16
   std::vector<Tgt> top, bot;
   const int64_t n = pl->n;
+  struct Mid { int64_t p, klo, khi, from_top, from_bot; };
+  std::vector<Mid> mids;  // the interpolated quantiles: each may be walked to from either end of the window
   for (int64_t p = 0; p < P; ++p) {
     int64_t klo, khi;
     int rc = hdp::quantile_param(q[p], n, &qp[p], &klo, &khi);
@@ -2426,13 +2428,39 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     } else {
       // lower = ascending[klo], upper = ascending[khi], khi = klo + 1 (or klo at the clamp): the
       // quantile is emitted at the later of the two ranks in merge order
-      const int64_t from_top = (n - 1 - klo) + 1;  // merge steps needed coming from the top
-      const int64_t from_bot = khi + 1;
-      const int same = (khi == klo) ? 1 : 0;
-      if (from_top <= from_bot)
-        top.push_back({int(n - 1 - klo), int(p) | ((same ? hdp::E_SAME : hdp::E_TOP_PAIR) << 16)});
+      mids.push_back({p, klo, khi, (n - 1 - klo) + 1, khi + 1});
+    }
+  }
+  {
+    // Which end each quantile is walked from.  The descending merge runs down to the deepest rank given to it, the
+    // ascending one up to its deepest, and a row pays for both walks: the lowest quantiles go to the bottom walk, the rest
+    // to the top walk, at the split that makes the SUM of the two depths smallest ("each to its nearer end" is one of the
+    // candidates and wins ties; ten quantiles around the median cost 817 steps from the top alone, 682 + 682 split at 0.5).
+    std::vector<size_t> order(mids.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return mids[a].klo < mids[b].klo; });
+    const int64_t base_top = top.empty() ? 0 : 1, base_bot = bot.empty() ? 0 : 1;
+    auto cost_of = [&](size_t n_bot) {  // the n_bot lowest quantiles from the bottom
+      int64_t st = base_top, sb = base_bot;
+      for (size_t i = 0; i < order.size(); ++i) {
+        const Mid &m = mids[order[i]];
+        if (i < n_bot) sb = std::max(sb, m.from_bot);
+        else st = std::max(st, m.from_top);
+      }
+      return st + sb;
+    };
+    size_t nearer = 0;  // the split "each to its nearer end" makes (from_top <= from_bot goes to the top)
+    while (nearer < order.size() && mids[order[nearer]].from_top > mids[order[nearer]].from_bot) ++nearer;
+    size_t best = nearer;
+    for (size_t k = 0; k <= order.size(); ++k)
+      if (cost_of(k) < cost_of(best)) best = k;
+    for (size_t i = 0; i < order.size(); ++i) {
+      const Mid &m = mids[order[i]];
+      const int same = (m.khi == m.klo) ? 1 : 0;
+      if (i >= best)
+        top.push_back({int(n - 1 - m.klo), int(m.p) | ((same ? hdp::E_SAME : hdp::E_TOP_PAIR) << 16)});
       else
-        bot.push_back({int(khi), int(p) | ((same ? hdp::E_SAME : hdp::E_BOT_PAIR) << 16)});
+        bot.push_back({int(m.khi), int(m.p) | ((same ? hdp::E_SAME : hdp::E_BOT_PAIR) << 16)});
     }
   }
   auto by_rank = [](const Tgt &a, const Tgt &b) { return a.rank < b.rank; };
@@ -2509,7 +2537,8 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     // tiered (more than 64 samples per column: top-side quantiles only, bottom walks would start in the global tail) or
     // with whole columns in LDS (up to 64 samples: any quantiles)
     const bool tiered = S > 64;
-    const bool cand = S >= 3 && S <= 100 && (!tiered || pl->steps_bot == 0) && (ngw0 == 1 || ngw0 == 2 || ngw0 == 4) &&
+    // (a walk deeper than ~8 samples per column and tier slot would spend its steps fetching from the global tail)
+    const bool cand = S >= 3 && S <= 100 && (!tiered || (pl->steps_bot == 0 && pl->steps_top <= 8 * hdp::kTierK)) && (ngw0 == 1 || ngw0 == 2 || ngw0 == 4) &&
                       pl->opt_lane != 0 && pl->opt_pipe != 0 && opt_rows <= 0 && hdp::env_option("HDP_THR_WHOLE", 1) != 0;
     if (cand && n_doy <= hdp::kWholeRows && n_doy > hdp::kLeanRows) {
       int ip = tiered ? hdp::kTierK + 3 : spad;
