@@ -264,7 +264,7 @@ def sharded_over_cells(fn, n_cells: int, axis: int, shard, empty=None):
     learned from the other ranks being unnecessary, the padding supplies it) -- and still takes part in the collectives.
     Every rank then agrees on success BEFORE the data collective, so an exception on one rank is raised on all."""
     rank, world = check_shard(shard)
-    if world == 1:
+    if world == 1 or n_cells == 0:   # (an empty grid: nothing to shard, every rank takes fn's own empty result)
         return fn(0, n_cells)
     lo, hi = shard_bounds(n_cells, world, rank)
     local, err = None, None
