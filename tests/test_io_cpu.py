@@ -166,3 +166,39 @@ def test_chunked_inputs_are_walked_block_by_block(store, monkeypatch):
     got = hdp_amd.metric.compute_individual_metrics(mda, whole_thr["temp_threshold"], defs, check_variables=False)
     assert calls == [5, 5]
     same_dataset(got, whole)
+
+
+def test_iter_bands_prefetches_the_next_band_and_keeps_order():
+    """hio.iter_bands: band k + 1 is fetched (isel + load) on a helper thread while the consumer holds band k; bands
+    come in order, each loaded exactly once, and an exception raised while fetching reaches the consumer."""
+    import threading
+    import time as _time
+    from hdp_amd import io as hio
+
+    log = []
+
+    class Lazy:
+        def __init__(self, lo=0, hi=10):
+            self.lo, self.hi = lo, hi
+
+        def isel(self, lat):
+            return Lazy(self.lo + lat.start, self.lo + lat.stop)
+
+        def load(self):
+            log.append(("load", self.lo, self.hi, threading.current_thread() is threading.main_thread()))
+            if self.lo == 6:
+                raise OSError("read failed")
+            _time.sleep(0.05)
+            return self
+
+    got = []
+    with pytest.raises(OSError, match="read failed"):
+        for (band,) in hio.iter_bands((Lazy(),), [(0, 3), (3, 6), (6, 9), (9, 10)]):
+            got.append((band.lo, band.hi))
+            _time.sleep(0.02)
+    assert got == [(0, 3), (3, 6)]                                  # the failing band is never delivered
+    assert [e[1:3] for e in log] == [(0, 3), (3, 6), (6, 9)]        # each band loaded once, in order
+    assert log[0][3] and not log[1][3] and not log[2][3]            # the first on the caller's thread, the rest prefetched
+    # two variables travel together (measure and thresholds of compute_metrics_io)
+    pairs = list(hio.iter_bands((Lazy(), Lazy(100, 110)), [(0, 5), (5, 10)]))
+    assert [(a.lo, b.lo) for a, b in pairs] == [(0, 100), (5, 105)]
