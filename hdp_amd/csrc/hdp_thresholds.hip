@@ -48,6 +48,7 @@ struct ThrDev {
   // lane-per-column kernel, tiered image: the top `tier_k` samples of a column live in LDS (column pitch `img_pitch`
   // words), samples tier_k.. in a per-workgroup global tail [parity][sample - tier_k][tail_pitch] (tier_k == S: all in LDS)
   int tier_k, img_pitch, tail_pitch;
+  int dual;  // lane kernel, blocked form: the descending and the ascending walk of a row on two different merging waves
   float *tail;
   const float *ninf;                 // four -inf words (what a slot without a sample loads)
   const int32_t *blk_grp_off, *grp_col;  // 16-byte gathers: first column of every group of four, per block
@@ -1011,7 +1012,7 @@ template <int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
                                                 const float *tail_cur, const uint32_t *flags, const uint16_t *cl, int r,
                                                 double *orow, const TgtLanes &tl_top, const TgtLanes &tl_bot,
-                                                int prio_phase = -1) {
+                                                int prio_phase = -1, int which = 0 /* 0: both walks, 1: top, 2: bottom */) {
   RowFlags rf{0, 0};
   uint32_t nan_or = 0;
 #pragma unroll
@@ -1022,8 +1023,8 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
     rf.n_neg += f & 0x7fff;
   }
   if (nan_or >> 31) rf.n_pos = -1;
-  merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_top, prio_phase);
-  merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_bot, prio_phase);
+  if (which != 2) merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_top, prio_phase);
+  if (which != 1) merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_bot, prio_phase);
   if (prio_phase >= 0) __builtin_amdgcn_s_setprio(3);
 }
 
@@ -1671,7 +1672,7 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
   off += 2 * size_t(flags_pitch) * 4;
   unsigned char *strips = smem + off;  // merge heads: 2nd..4th of every (group, row), see merge_row_lean
-  off += lean_strip_bytes<NG, ROWS>();
+  off += lean_strip_bytes<NG, ROWS>() * (pd.dual ? 2 : 1);  // dual: one set per walk direction
   uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][4 * NG] local columns of this block's windows (slots past W: the pseudo column)
 
   const int nb = pd.n_blocks;
@@ -1725,7 +1726,12 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   if (producer) __builtin_amdgcn_s_setprio(0);
   else __builtin_amdgcn_s_setprio(3);
   const int pw = rank - n_merge;      // producer index
-  const int mrow = rank * 64 + lane;  // merging waves: row of the block this lane merges
+  // merging waves: row of the block this lane merges.  Dual form (both walks long): the first half of the merging waves
+  // walks the rows down from the top, the second half walks the same rows up from the bottom, each with its own strips --
+  // two chains of half the length per row instead of one.
+  const int nm_rows = pd.dual ? (n_merge >> 1) : n_merge;
+  const int walk = pd.dual ? (rank < nm_rows ? 1 : 2) : 0;
+  const int mrow = (pd.dual ? (rank % max(nm_rows, 1)) : rank) * 64 + lane;
 
   // Two loops, one per role, with the same two barriers per item ("image free / keys sorted", "image written"):
   // s_barrier counts wave arrivals, so waves may reach it from different code.  Written as one loop, the sorted keys
@@ -1882,9 +1888,10 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
 #if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 1))
         // ranks >= 4 are the second merging wave of their SIMD (roles above: one merging wave per SIMD first)
-        merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips,
+        merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf),
+                            strips + (walk == 2 ? lean_strip_bytes<NG, ROWS>() : 0),
                             tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow, tl_top, tl_bot,
-                            (n_merge > 4 && ROWS == kWholeRows) ? int(rank >= 4) : -1);
+                            (n_merge > 4 && ROWS == kWholeRows) ? int(rank >= 4) : -1, walk);
 #endif
       }
       if (clocked || clocked_w) c1 = __builtin_readcyclecounter();
@@ -2176,7 +2183,7 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
              "thresholds_lane_kernel<N=%d,NG=%d%s> (one lane per column: register merge-exchange sort; %d merging waves; "
              "%d rows x %d blocks, %zu B LDS%s)",
              plan->lane_n, plan->Wp >> 2,
-             plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : (plan->n_blocks == 1 && plan->RP > hdp::kLeanRows ? ",whole-cell" : ""), plan->n_merge,
+             plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : (plan->n_blocks == 1 && plan->RP > hdp::kLeanRows ? ",whole-cell" : (plan->lane_dual ? ",dual" : "")), plan->lane_n_merge,
              plan->rows_per_block, plan->n_blocks, plan->lane_lds_bytes,
              plan->lane_tier_k < plan->S ? "; top 60 samples of a column in LDS, the rest in a global tail" : "");
   else if (v.pipe)
@@ -2235,6 +2242,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.grp_col = plan->grp_col.as<int32_t>();
   pd.SL = 8 * plan->lpc;
   pd.n_merge = plan->n_merge;
+  pd.dual = 0;
   pd.tixl = plan->tixl.as<int32_t>();
   pd.blk_tixl_off = plan->blk_tixl_off.as<int32_t>();
   pd.tier_k = plan->lane_tier_k;
@@ -2258,6 +2266,8 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   const ThrVariant var = thr_variant(plan, pd.debug);
   pd.select = var.select;
   if (var.lane) {
+    pd.n_merge = plan->lane_n_merge;
+    pd.dual = plan->lane_dual ? 1 : 0;
     switch (plan->lane_n) {
       case 8: return launch_thr_lane<8>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
       case 16: return launch_thr_lane<16>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
@@ -2650,6 +2660,35 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     b += (size_t(rows) * 4 * ngw * 2 + 15) & ~size_t(15);
     pl->lane_lds_bytes = whole ? whole_lds : b;
     if (!whole && (b > kMaxLds || rows > hdp::kLeanRows)) pl->lane = false;
+    // Dual form of the blocked kernel: when BOTH walks are long (quantile sets that reach deep from both ends of the
+    // window) a row's descending and ascending merge run on two different waves, each with its own head strips -- two
+    // chains of half the length, and the kernel is bound by the length of its chains.  Blocks shrink until two
+    // workgroups (each with twice the merging waves and twice the strips) still share a CU.  HDP_THR_DUAL=0 / 1.
+    const long long dual_opt = hdp::env_option("HDP_THR_DUAL", -1);
+    const bool dual_want = dual_opt > 0 || (dual_opt < 0 && pl->steps_top >= 96 && pl->steps_bot >= 96);
+    if (pl->lane && !whole && !rows_forced && dual_want && pl->steps_top > 0 && pl->steps_bot > 0) {
+      const int tpw = hdp::lane_tasks_per_wave_rt(lane_n);
+      for (int r = std::min(rows, (int)hdp::kLeanRows); r >= 16; --r) {
+        const int nb = int((n_doy + r - 1) / r);
+        const int rb = int((n_doy + nb - 1) / nb);  // balanced blocks
+        int c2 = 0;
+        if (max_lds_for_rows(rb, &c2) > kMaxLds) continue;
+        const int nm2 = 2 * ((rb + 63) / 64);
+        const int n_tasks = (c2 + 63) / 64;
+        if (nm2 + (n_tasks + tpw - 1) / tpw > hdp::kThrThreads / 64) continue;
+        size_t bd = (size_t(c2 + 1) * ip * 4 + 15) & ~size_t(15);
+        bd += 2 * ((size_t(c2) * 4 + 15) & ~size_t(15));
+        bd += 2 * size_t(ngw) * hdp::kLeanRows * 24;
+        bd += (size_t(rb) * 4 * ngw * 2 + 15) & ~size_t(15);
+        if (bd > (kMaxLds + 1024) / 2 - 512) continue;  // two workgroups per CU
+        rows = rb;
+        cm = c2;
+        pipe = pipe_ok(rows, cm);
+        pl->lane_dual = true;
+        pl->lane_lds_bytes = bd;
+        break;
+      }
+    }
   }
   if (lpc && !pipe && !lane && !rows_forced) {
     for (int r = rows - 1; r >= std::max(1, rows / 2); --r) {
@@ -2665,6 +2704,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   pl->pipe = pipe;
   pl->lpc = lpc;
   pl->n_merge = (rows + 63) / 64;
+  pl->lane_n_merge = pl->lane_dual ? 2 * pl->n_merge : pl->n_merge;
   pl->rows_per_block = rows;
   pl->RP = (rows + 63) & ~63;
   pl->ncols_max = cm;

@@ -71,7 +71,7 @@ def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
         want = c_oracle.thresholds(x, win, q)
 
     def run(**env):
-        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE", "HDP_THR_WHOLE"):
+        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE", "HDP_THR_WHOLE", "HDP_THR_DUAL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -80,6 +80,9 @@ def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
     got = run()                                        # lane-per-column kernel where the plan allows it
     assert same_f64(got, want)
     assert same_f64(run(HDP_THR_WHOLE="0"), want)     # its blocked form where the default is the whole-cell one
+    # blocked form with the two walks of a row on different merging waves (plans with a top AND a bottom walk), and without
+    assert same_f64(run(HDP_THR_WHOLE="0", HDP_THR_DUAL="1"), want)
+    assert same_f64(run(HDP_THR_WHOLE="0", HDP_THR_DUAL="0"), want)
     assert same_f64(run(HDP_THR_LANE="0"), want)      # pipelined kernel (16-byte gathers on regular calendars)
     assert same_f64(run(HDP_THR_LANE="0", HDP_THR_VEC="0"), want)   # pipelined kernel, one dword per (column, sample)
     assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="0"), want)   # one workgroup per cell, merge
@@ -157,8 +160,9 @@ def test_random_calendars_windows_and_quantiles(seed, monkeypatch):
     with np.errstate(invalid="ignore"):
         want = c_oracle.thresholds(x, win, q)
     for env in ({}, {"HDP_THR_WHOLE": "0"}, {"HDP_THR_LANE": "0"}, {"HDP_THR_LANE": "0", "HDP_THR_VEC": "0"},
-                {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "0"}, {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "1"}):
-        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE", "HDP_THR_WHOLE"):
+                {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "0"}, {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "1"},
+                {"HDP_THR_WHOLE": "0", "HDP_THR_DUAL": "1"}, {"HDP_THR_WHOLE": "0", "HDP_THR_DUAL": "0"}):
+        for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE", "HDP_THR_WHOLE", "HDP_THR_DUAL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
