@@ -1807,27 +1807,6 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
 #if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 2))
             sort_lane_desc<N>(v[k]);
 #endif
-            if constexpr (TIER) {
-              // Tiered image: samples kTierK.. of every column go to the workgroup's global tail [sample - kTierK][column]
-              // (a store instruction writes 64 adjacent columns).  The tail is double-buffered by item parity, so THIS
-              // item's half is free while the merge of the previous item still reads the other one: the stores, and the
-              // wait for them, happen here -- in the time the producers would spend at the barrier below -- and not
-              // between the two barriers, where the merging waves would wait for them (round 3).
-              if (lc < ncols) {
-                const float *tbase = tail_wg + size_t(s & 1) * tail_half;  // wave-uniform
-                const uint32_t trow = uint32_t(pd.tail_pitch) * 4u;
-                uint32_t toff = uint32_t(lc) * 4u;  // one running byte offset (see the loads)
-#pragma unroll
-                for (int i = kTierK; i < N; ++i) {
-                  // slots past S (padding) all land on the spare row behind the last sample's
-                  const uint32_t o = (i < lane_first_pad_slot(N)) ? toff : uint32_t(lc) * 4u + uint32_t(min(i, S_rt) - kTierK) * trow;
-                  asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(v[k][i]), "s"(tbase) : "memory");
-                  toff += trow;
-                  asm volatile("" : "+v"(toff));
-                }
-              }
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail stores are asm: no compiler-made wait counts them
-            }
           }
         }
       }
@@ -1854,11 +1833,27 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
               }
               col[S_rt] = __uint_as_float(kRawMin);  // loses every descending walk
             } else {
-              // tiered: the top kTierK samples to LDS and the marker behind them (the rest went to the global tail above)
+              // tiered: the top kTierK samples to LDS, the marker behind them, the rest to the workgroup's global tail
+              // [sample - kTierK][column] (a store instruction writes 64 adjacent columns); slots past S land on a
+              // spare row
+              const float *tbase = tail_wg + size_t(s & 1) * tail_half;  // wave-uniform
+              uint32_t toff = uint32_t(lc) * 4u;                          // one running byte offset (see the loads)
+              const uint32_t trow = uint32_t(pd.tail_pitch) * 4u;
 #pragma unroll
-              for (int i = 0; i < kTierK && i < N; ++i) col[i] = __int_as_float(v[k][i]);
+              for (int i = 0; i < N; ++i) {
+                if (i < kTierK) {
+                  col[i] = __int_as_float(v[k][i]);
+                } else {
+                  // slots past S (padding) all land on the spare row behind the last sample's
+                  const uint32_t o = (i < lane_first_pad_slot(N)) ? toff : uint32_t(lc) * 4u + uint32_t(min(i, S_rt) - kTierK) * trow;
+                  asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(v[k][i]), "s"(tbase) : "memory");
+                  toff += trow;
+                  asm volatile("" : "+v"(toff));
+                }
+              }
               col[kTierK] = __uint_as_float(0x7ff00000u | uint32_t(lc));
               col[kTierK + 1] = __uint_as_float(kRawMin);  // what the heads of window slots past W read
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail stores are asm: the barrier's own wait does not count them
             }
             col[-1] = __uint_as_float(kRawMax);    // loses every ascending walk
           }
