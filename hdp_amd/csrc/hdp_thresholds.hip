@@ -1672,7 +1672,9 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
   off += 2 * size_t(flags_pitch) * 4;
   unsigned char *strips = smem + off;  // merge heads: 2nd..4th of every (group, row), see merge_row_lean
-  off += lean_strip_bytes<NG, ROWS>() * (pd.dual ? 2 : 1);  // dual: one set per walk direction
+  constexpr bool kCanDual = ROWS == kLeanRows;  // the whole-cell form never splits the walks: nothing of this in its code
+  const bool dual = kCanDual && pd.dual != 0;
+  off += lean_strip_bytes<NG, ROWS>() * (dual ? 2 : 1);  // dual: one set per walk direction
   uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][4 * NG] local columns of this block's windows (slots past W: the pseudo column)
 
   const int nb = pd.n_blocks;
@@ -1729,9 +1731,9 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   // merging waves: row of the block this lane merges.  Dual form (both walks long): the first half of the merging waves
   // walks the rows down from the top, the second half walks the same rows up from the bottom, each with its own strips --
   // two chains of half the length per row instead of one.
-  const int nm_rows = pd.dual ? (n_merge >> 1) : n_merge;
-  const int walk = pd.dual ? (rank < nm_rows ? 1 : 2) : 0;
-  const int mrow = (pd.dual ? (rank % max(nm_rows, 1)) : rank) * 64 + lane;
+  const int nm_rows = dual ? (n_merge >> 1) : n_merge;
+  const int walk = dual ? (rank < nm_rows ? 1 : 2) : 0;
+  const int mrow = (dual ? (rank % max(nm_rows, 1)) : rank) * 64 + lane;
 
   // Two loops, one per role, with the same two barriers per item ("image free / keys sorted", "image written"):
   // s_barrier counts wave arrivals, so waves may reach it from different code.  Written as one loop, the sorted keys
@@ -1883,10 +1885,14 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
 #if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 1))
         // ranks >= 4 are the second merging wave of their SIMD (roles above: one merging wave per SIMD first)
-        merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf),
-                            strips + (walk == 2 ? lean_strip_bytes<NG, ROWS>() : 0),
-                            tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow, tl_top, tl_bot,
-                            (n_merge > 4 && ROWS == kWholeRows) ? int(rank >= 4) : -1, walk);
+        if constexpr (kCanDual)
+          merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf),
+                              strips + (walk == 2 ? lean_strip_bytes<NG, ROWS>() : 0),
+                              tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow, tl_top, tl_bot, -1, walk);
+        else
+          merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips,
+                              tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow, tl_top, tl_bot,
+                              n_merge > 4 ? int(rank >= 4) : -1);
 #endif
       }
       if (clocked || clocked_w) c1 = __builtin_readcyclecounter();
