@@ -55,6 +55,7 @@ CONFIGS = {
     "tiny5": (10, 8, 16, 3, PERCENTILES_C5, DEFINITIONS_C5),
 }
 PARITY_CELLS = 1024   # cells of the parity sample, strided over every band of the rank's shard (>= 1000)
+CPU_CELLS = 4096      # cells of the all-threads CPU-baseline sample (the parity cells first, then more of the same bands)
 
 
 def main():
@@ -356,26 +357,44 @@ def main():
             met_gpu = np.concatenate(met_g, axis=3).reshape(P, D, M * ns, 4, Y).astype(np.int64)
             hemi = np.tile(np.concatenate(hemi), M)
             n_south = int(hemi[:ns].sum())
-            tc = time.perf_counter()
             th_cpu = c_oracle.thresholds(xs_b, win, PERC)
             met_cpu = c_oracle.metrics(xs_m, np.concatenate([th_cpu] * M), doy_map, DEFS, north, south, hemi)
-            cpu_s = time.perf_counter() - tc
             parity = {"cells": int(ns), "southern_cells": n_south, "northern_cells": int(ns - n_south),
                       "bands_sampled": int(sum(1 for c in band_cells if c)),
                       "thresholds_bit_exact": bool(np.array_equal(th_gpu, th_cpu, equal_nan=True)),
                       "metrics_bit_exact": bool(np.array_equal(met_gpu, met_cpu))}
+            # The all-threads CPU baseline: CPU_CELLS cells of the band still resident (series copied out of the device
+            # buffers the kernels read), both passes, timed; the same cells' GPU results are compared once more.
+            nbl = band_cells[n_bands - 1] if band_cells[n_bands - 1] else nb0
+            ncpu = int(min(CPU_CELLS if M == 1 else max(64, CPU_CELLS // (4 * M)), nbl))
+            idc = torch.from_numpy(np.unique(np.linspace(0, nbl - 1, ncpu).astype(np.int64))).to(dev)
+            ncpu = int(idc.numel())
+            cb = xb[: nbl * M * T * 4].view(torch.float32).view(nbl, M * T)[idc].cpu().numpy()
+            cm = xm[: M * nbl * T * 4].view(torch.float32).view(M, nbl, T)[:, idc].cpu().numpy().reshape(M * ncpu, T)
+            lat_last = lat_cells[(n_bands - 1) * bc + idc.cpu().numpy()] if band_cells[n_bands - 1] else lat_cells[idc.cpu().numpy()]
+            ch = np.tile((lat_last < 0).astype(np.uint8), M)
+            tc = time.perf_counter()
+            th_c = c_oracle.thresholds(cb, win, PERC)
+            c_oracle.metrics(cm, np.concatenate([th_c] * M), doy_map, DEFS, north, south, ch)
+            cpu_s = time.perf_counter() - tc
             # 1-thread figure on a few cells of the same sample
-            n1 = int(max(1, min(ns, 8)))
+            n1 = int(max(1, min(ncpu, 16)))
             one = c_oracle.set_threads(1)
             t1 = time.perf_counter()
-            th1 = c_oracle.thresholds(xs_b[:n1], win, PERC)
-            c_oracle.metrics(xs_m.reshape(M, ns, T)[:, :n1].reshape(M * n1, T), np.concatenate([th1] * M), doy_map,
-                             DEFS, north, south, np.tile(hemi[:n1], M))
+            th1 = c_oracle.thresholds(cb[:n1], win, PERC)
+            c_oracle.metrics(cm.reshape(M, ncpu, T)[:, :n1].reshape(M * n1, T), np.concatenate([th1] * M), doy_map,
+                             DEFS, north, south, np.tile(ch[:n1], M))
             one_s = time.perf_counter() - t1
             c_oracle.set_threads(cores)
+            host = host_cpu()
             cpu = None if world > 1 else {   # reported at N = 1 only (torchrun pins OMP_NUM_THREADS=1)
-                "value": 2.0 * ns * M * T / cpu_s, "unit": "cell-days/s", "cores": cores, "kind": "port",
-                "sample": f"{ns} cells strided over the {n_bands} band(s) of the same workload (T={T}, P={P}, D={D}), both "
+                "value": 2.0 * ncpu * M * T / cpu_s, "unit": "cell-days/s",
+                "cores": int(host["physical_cores"] or cores), "threads": cores, "kind": "port",
+                "cpu_model": host["model"], "physical_cores": host["physical_cores"], "logical_cpus": host["logical_cpus"],
+                "sockets": host["sockets"],
+                "thread_binding": (f"OpenMP, {cores} threads (omp_get_max_threads), no explicit pinning (OMP_PROC_BIND="
+                                   f"{os.environ.get('OMP_PROC_BIND', 'unset')}); {host['affinity_cpus']} CPUs in the affinity mask"),
+                "sample": f"{ncpu} cells strided over one band of the same workload (T={T}, P={P}, D={D}), both "
                           f"passes, {cpu_s:.1f} s; oracle/hdp_oracle.c (reference algorithm restated in C, OpenMP over cells)",
                 "one_thread": {"value": 2.0 * n1 * M * T / one_s, "unit": "cell-days/s", "cores": int(one),
                                "sample": f"first {n1} cells of that sample, {one_s:.1f} s"}}
@@ -402,6 +421,11 @@ def main():
             "wall_ms_per_step": wall * 1e3 / max(1, args.steps),
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kern, "pre_step": pre_step, "layout_tm": layout_tm,
             "allgather": allgather, "parity_sample": parity, "device": _lib.device_info(),
+            # which runtime libraries this process mapped: the first thing a failed multi-GPU run's log must say
+            "runtime": dict(_lib.runtime_report(), torch=torch.__version__,
+                            collective_transport=(None if world == 1 else
+                                                  ("library RCCL communicator (hdp_comm_*)" if hdist.comm_ready() else
+                                                   f"torch.distributed {args.backend}"))),
         }
         print(json.dumps(line), flush=True)
 
@@ -442,6 +466,34 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cpu():
+    """{model, physical_cores, logical_cpus, sockets} from /proc/cpuinfo (the CPU baseline names its host)"""
+    model, cores, sockets, logical = None, set(), set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+                sockets.add(v)
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return {"model": model, "physical_cores": len(cores) or None, "logical_cpus": logical or os.cpu_count(),
+            "sockets": len(sockets) or None, "affinity_cpus": len(os.sched_getaffinity(0))}
+
+
 def spawn_ranks(n, script=None, argv=None):
     """Start `n` fresh rank processes of this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as a
     launcher would) and wait for them.  Rank 0 inherits stdout, so its JSON line is this command's line; the return
@@ -461,12 +513,30 @@ def spawn_ranks(n, script=None, argv=None):
         env.setdefault("OMP_NUM_THREADS", "1" if r else str(os.cpu_count() or 1))
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)]
                                       + list(sys.argv[1:] if argv is None else argv), env=env))
-    worst = 0
+    # Poll every rank: the first one that exits non-zero (or is killed) takes the others down after a short grace period,
+    # as torchrun does -- otherwise they sit in the rendezvous or a collective until torch's own timeout, minutes later.
+    worst, failed_at = 0, None
     try:
-        for pr in procs:
-            rc = pr.wait()
-            rc = 128 - rc if rc < 0 else rc
-            worst = max(worst, rc)
+        while True:
+            alive = 0
+            for pr in procs:
+                rc = pr.poll()
+                if rc is None:
+                    alive += 1
+                    continue
+                rc = 128 - rc if rc < 0 else rc
+                worst = max(worst, rc)
+                if rc and failed_at is None:
+                    failed_at = time.monotonic()
+            if not alive:
+                break
+            if failed_at is not None:
+                late = time.monotonic() - failed_at
+                if late > 1.0:      # a moment for the others to fail on their own account (and say why) first
+                    for pr in procs:
+                        if pr.poll() is None:
+                            (pr.kill if late > 11.0 else pr.terminate)()
+            time.sleep(0.05)
     except KeyboardInterrupt:
         for pr in procs:
             pr.terminate()

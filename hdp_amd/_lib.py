@@ -64,6 +64,7 @@ SIGNATURES = {
     "hdp_metrics_f32_layout_i16": (C.c_int, [vp, i64, i64, i64, i64, vp, i64, i64, i64, vp, vp, i64, vp, vp, vp, i64, vp]),
     "hdp_metrics_f32_planes_i64_sharded": (C.c_int, [vp, i64, i64, i64, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp,
                                                      i64, i64, vp, P(i64)]),
+    "hdp_metrics_planes_i64_regroup": (C.c_int, [vp, i64, i64, i64, i64, i64, i64, vp]),
     "hdp_index_heatwaves": (C.c_int, [vp, i64, i64, i64, i64, i64, vp]),
     "hdp_season_metrics": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
     "hdp_indicate_hot_days": (C.c_int, [vp, i64, i64, vp, i64, vp, vp]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "hdp_comm_unique_id": (C.c_int, [vp]),
     "hdp_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int]),
     "hdp_comm_destroy": (C.c_int, []),
+    "hdp_rccl_version": (C.c_int, [P(C.c_int)]),
     "hdp_comm_rank": (C.c_int, []),
     "hdp_comm_world": (C.c_int, []),
     "hdp_allgather_dev": (C.c_int, [vp, sz, vp, vp]),
@@ -114,6 +116,11 @@ def _share_hip_runtime():
         return "system"
     libdir = os.path.join(os.path.dirname(spec.origin), "lib")
     mapped = []
+    # NOT librccl: libhdp_hip.so NEEDs librccl.so.1 and the wheel bundles one under the same soname, so whichever copy is
+    # mapped first serves both the library's communicator and a later torch.distributed nccl backend -- but mapping the
+    # wheel's copy from here, ahead of the rest of torch's libraries, ends the process in "double free or corruption"
+    # (measured, round 4).  A process that wants torch's RCCL imports torch first (bench.py does); runtime_report() says
+    # which copy a run had.
     for name in ("libhsa-runtime64.so", "libamdhip64.so"):
         path = os.path.join(libdir, name)
         if os.path.exists(path):
@@ -174,3 +181,28 @@ def ensure_device(device=None):
 
 def device_info():
     return ensure_device().hdp_device_info().decode()
+
+
+def mapped_libraries(names=("librccl", "libamdhip64", "libhsa-runtime64", "libhdp_hip")):
+    """Resolved paths of the runtime libraries this process has mapped (/proc/self/maps): which librccl / libamdhip64 /
+    libhsa-runtime64 a failing multi-GPU run was using is the first question its log must answer."""
+    found = {n: [] for n in names}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                base = os.path.basename(path)
+                for n in names:
+                    if base.startswith(n + ".so") and path not in found[n]:
+                        found[n].append(path)
+    except OSError:
+        pass
+    return found
+
+
+def runtime_report():
+    """{hip_runtime, mapped: {lib: [paths]}, rccl_version}: goes into bench.py's JSON line."""
+    lib = load()
+    ver = C.c_int(0)
+    rc = lib.hdp_rccl_version(C.byref(ver))
+    return {"hip_runtime": hip_runtime, "mapped": mapped_libraries(), "rccl_version": int(ver.value) if rc == HDP_OK else None}

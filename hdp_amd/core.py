@@ -132,24 +132,47 @@ def compute_heatwave_metric_planes_sharded(x, thresholds, doy_map, hw_definition
     result is all-gathered on the device and widened once there.  -> (int64 [4, P, D, n_mem * n_total, Y], bytes this
     rank handed to the collective); every rank receives the whole grid's planes."""
     lib = _lib.ensure_device()
-    x, sc, st = _as_series_2d(x)
-    thr = np.ascontiguousarray(thresholds, dtype=np.float64)
-    dm = np.ascontiguousarray(doy_map, dtype=np.int64)
-    defs = np.ascontiguousarray(np.asarray(hw_definitions, dtype=np.int64).reshape(-1, 3))
-    north = np.ascontiguousarray(north, dtype=np.int64).reshape(-1, 2)
-    south = np.ascontiguousarray(south, dtype=np.int64).reshape(-1, 2)
-    hemi = np.ascontiguousarray(is_south, dtype=np.uint8)
-    n, T = x.shape
-    n_loc, n_doy, P = thr.shape
-    D, Y = defs.shape[0], north.shape[0]
-    if n != n_mem * n_loc or dm.size != T or hemi.size != n or south.shape[0] != Y:
-        raise ValueError("inconsistent table sizes")
-    out = np.zeros((4, P, D, int(n_mem) * int(n_total), Y), dtype=np.int64)
+    # The call is a collective: a rank that fails in its own preparation (shapes that do not fit, an allocation) must
+    # still meet the others in the library's status exchange, or they wait in it for ever.  Such a rank makes the C call
+    # with arguments the library refuses (n_mem = 0): every rank then gets an error back, and this one re-raises its own.
+    try:
+        x, sc, st = _as_series_2d(x)
+        thr = np.ascontiguousarray(thresholds, dtype=np.float64)
+        dm = np.ascontiguousarray(doy_map, dtype=np.int64)
+        defs = np.ascontiguousarray(np.asarray(hw_definitions, dtype=np.int64).reshape(-1, 3))
+        north = np.ascontiguousarray(north, dtype=np.int64).reshape(-1, 2)
+        south = np.ascontiguousarray(south, dtype=np.int64).reshape(-1, 2)
+        hemi = np.ascontiguousarray(is_south, dtype=np.uint8)
+        n, T = x.shape
+        n_loc, n_doy, P = thr.shape
+        D, Y = defs.shape[0], north.shape[0]
+        if n != n_mem * n_loc or dm.size != T or hemi.size != n or south.shape[0] != Y:
+            raise ValueError("inconsistent table sizes")
+        out = np.zeros((4, P, D, int(n_mem) * int(n_total), Y), dtype=np.int64)
+    except Exception:
+        lib.hdp_metrics_f32_planes_i64_sharded(None, 0, 0, 1, 1, 1, None, 1, 1, None, None, 1, None, None, None, 0, 0, None,
+                                               None)
+        raise
     wire = C.c_int64(0)
     _lib.check(lib.hdp_metrics_f32_planes_i64_sharded(_ptr(x), int(n_mem), n_loc, T, sc, st, _ptr(thr), n_doy, P, _ptr(dm),
                                                       _ptr(defs), D, _ptr(north), _ptr(south), _ptr(hemi), Y,
                                                       int(n_total), _ptr(out), C.byref(wire)))
     return out, int(wire.value)
+
+
+def regroup_gathered_planes(gathered, world, n_mem, n_total):
+    """The widening / regrouping half of the sharded call on a host-built gathered buffer (no communicator): gathered
+    int16 [world, 4, P, D, Y, n_mem * shard], shard = ceil(n_total / world), zero columns past a rank's cells ->
+    int64 [4, P, D, n_mem * n_total, Y].  Unit-level: pins the multi-rank layout on one GPU."""
+    lib = _lib.ensure_device()
+    g = np.ascontiguousarray(gathered, dtype=np.int16)
+    w, four, P, D, Y, pad = g.shape
+    shard = -(-int(n_total) // int(world)) if n_total else 0
+    if w != world or four != 4 or pad != n_mem * shard:
+        raise ValueError("gathered buffer does not have the layout [world, 4, P, D, Y, n_mem * ceil(n_total / world)]")
+    out = np.zeros((4, P, D, int(n_mem) * int(n_total), Y), dtype=np.int64)
+    _lib.check(lib.hdp_metrics_planes_i64_regroup(_ptr(g), int(world), int(n_mem), int(n_total), P, D, Y, _ptr(out)))
+    return out
 
 
 def compute_heatwave_metric_planes(x, thresholds, doy_map, hw_definitions, north, south, is_south):

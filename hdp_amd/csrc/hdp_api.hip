@@ -7,12 +7,15 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <future>
 #include <string>
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 namespace hdp {
 
@@ -542,14 +545,6 @@ int hdp_metrics_plan_create(const int64_t *doy_map, int64_t T, int64_t n_doy, co
   pl->opt_years = (int32_t)env_option("HDP_METRICS_YEARS", 1);   // 0: never, 1: records of >= 24 years, 2: any length
   pl->opt_years_lds = (int32_t)std::min<long long>(65536, std::max<long long>(0, env_option("HDP_METRICS_YEARS_LDS", 16384)));
   pl->opt_batch = std::max<long long>(0, env_option("HDP_METRICS_BATCH", 0));
-  {  // queue entries per lane of metrics_kernel_cells16q (32, 48 or 64); 0: the lock-step kernel
-#ifdef HDP_PROTO_QUEUE
-    const long long qv = env_option("HDP_METRICS_QUEUE", 0);
-    pl->opt_queue = qv <= 0 ? 0 : (qv >= 64 ? 64 : (qv >= 48 ? 48 : 32));
-#else
-    pl->opt_queue = 0;  // the prototype kernel is not in this build
-#endif
-  }
   pl->opt_simple = env_option("HDP_METRICS_SIMPLE", 1) != 0;   // short path for pairs of definitions with max_break = 0
   pl->Ypitch = (Y + 15) & ~int64_t(15);  // 32-byte rows: sector-aligned packed stores
   int64_t dmax = 1;
@@ -759,6 +754,7 @@ int hdp_metrics_f32_layout_i16(const float *x, int64_t n_cells, int64_t T, int64
 
 static ncclComm_t g_comm = nullptr;
 static int g_comm_rank = -1, g_comm_world = 0;
+static DevBuf g_comm_stat;  // [world + 1] int32: the status words of the sharded calls (allocated with the communicator)
 
 // Sharded form of hdp_metrics_f32_planes_i64 (the reference's split is the dask graph of metric.py:444-452):
 // this rank holds the `n_loc` cells [rank * shard, rank * shard + n_loc) of a grid of `n_total` cells, shard =
@@ -775,22 +771,41 @@ int hdp_metrics_f32_planes_i64_sharded(const float *x, int64_t n_mem, int64_t n_
                                        int64_t *out, int64_t *wire_bytes) {
   HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
   HDP_REQUIRE(g_comm, HDP_EINVAL, "no communicator (hdp_comm_init_rank)");
-  HDP_REQUIRE(n_mem >= 1 && n_loc >= 0 && n_total >= 0 && P >= 1 && D >= 1 && Y >= 0, HDP_EINVAL, "bad sizes");
-  const int64_t world = g_comm_world, rank = g_comm_rank;
-  const int64_t shard = (n_total + world - 1) / world;
-  const int64_t lo = std::min(n_total, rank * shard), hi = std::min(n_total, (rank + 1) * shard);
-  HDP_REQUIRE(n_loc == hi - lo, HDP_EINVAL, "rank %d of %d owns %lld cells of a grid of %lld, not %lld", (int)rank,
-              (int)world, (long long)(hi - lo), (long long)n_total, (long long)n_loc);
   if (wire_bytes) *wire_bytes = 0;
-  if (n_total == 0 || Y == 0) return HDP_OK;
-  HDP_REQUIRE(out, HDP_EINVAL, "NULL output");
+  const int64_t world = g_comm_world, rank = g_comm_rank;
+  // Everything a rank can fail at BEFORE the data collective -- argument checks, the shard / gathered buffers (the
+  // gathered one is world x the shard: the likeliest out-of-memory), the local pass itself -- is recorded in local_rc
+  // instead of returned, and every rank then meets in a 4-byte status all-gather (its device words were allocated with the
+  // communicator, so nothing can fail between here and there).  The data all-gather runs only when every rank reported
+  // success: one failing rank makes every rank return an error instead of leaving the others blocked in ncclAllGather.
+  int local_rc = HDP_OK;
+  std::string local_msg;
+  auto fail = [&](int code, const char *fmt, auto... a) {
+    if (local_rc != HDP_OK) return;
+    local_rc = set_error(code, fmt, a...);
+    local_msg = hdp_last_error();
+  };
+  if (!(n_mem >= 1 && n_loc >= 0 && n_total >= 0 && P >= 1 && D >= 1 && Y >= 0)) fail(HDP_EINVAL, "bad sizes");
+  const int64_t shard = world > 0 ? (std::max<int64_t>(n_total, 0) + world - 1) / world : 0;
+  const int64_t lo = std::min(n_total, rank * shard), hi = std::min(n_total, (rank + 1) * shard);
+  if (local_rc == HDP_OK && n_loc != hi - lo)
+    fail(HDP_EINVAL, "rank %d of %d owns %lld cells of a grid of %lld, not %lld", (int)rank, (int)world,
+         (long long)(hi - lo), (long long)n_total, (long long)n_loc);
+  const bool empty = local_rc == HDP_OK && (n_total == 0 || Y == 0);   // the same on every rank that passed the checks
+  if (local_rc == HDP_OK && !empty && !out) fail(HDP_EINVAL, "NULL output");
   const int64_t rows = 4 * P * D * Y;          // rows of the device layout
   const int64_t pad = n_mem * shard;           // series columns per rank, equal on every rank
-  const size_t shard_bytes = size_t(rows) * pad * 2;
+  const size_t shard_bytes = local_rc == HDP_OK ? size_t(rows) * pad * 2 : 0;
   DevBuf dlocal, dgath;
-  HDP_HIP_TRY(dlocal.alloc(shard_bytes));
-  HDP_HIP_TRY(dgath.alloc(shard_bytes * world));
-  HDP_HIP_TRY(hipMemsetAsync(dlocal.p, 0, shard_bytes, g_stream));
+  const char *inject = getenv("HDP_FAULT_INJECT");   // tests: "sharded_alloc" fails the gathered buffer's allocation
+  if (local_rc == HDP_OK && !empty) {
+    hipError_t e = dlocal.alloc(shard_bytes);
+    if (e == hipSuccess) e = (inject && !strcmp(inject, "sharded_alloc")) ? hipErrorOutOfMemory : dgath.alloc(shard_bytes * world);
+    if (e == hipSuccess) e = hipMemsetAsync(dlocal.p, 0, shard_bytes, g_stream);
+    if (e != hipSuccess)
+      fail(HDP_ENOMEM, "allocating the shard (%zu B) and gathered (%zu B) metric buffers failed: %s", shard_bytes,
+           shard_bytes * size_t(world), hipGetErrorString(e));
+  }
   auto sink = [&](int64_t c0, int64_t nc, int64_t /*chunk*/, const int16_t *dout) -> int {
     // series s = m * n_loc + c of the call -> column m * shard + c of the shard buffer: one 2-D copy per member touched
     for (int64_t s0 = c0; s0 < c0 + nc;) {
@@ -802,32 +817,36 @@ int hdp_metrics_f32_planes_i64_sharded(const float *x, int64_t n_mem, int64_t n_
     }
     return HDP_OK;
   };
-  // A rank whose local pass fails still enters the collectives (with whatever its shard buffer holds) and reports its
-  // code through a second, 4-byte all-gather: every rank then returns an error instead of one rank leaving the others
-  // blocked in ncclAllGather.
-  int local_rc = HDP_OK;
-  std::string local_msg;
-  if (n_loc > 0) {
-    local_rc = metrics_host_chunks(x, n_mem * n_loc, T, stride_cell, stride_time, thr, n_loc, n_doy, P, doy_map, defs,
-                                   D, north, south, is_south, Y, 0, sink);
-    if (local_rc != HDP_OK) local_msg = hdp_last_error();
+  if (local_rc == HDP_OK && !empty && n_loc > 0) {
+    const int rc = metrics_host_chunks(x, n_mem * n_loc, T, stride_cell, stride_time, thr, n_loc, n_doy, P, doy_map, defs,
+                                       D, north, south, is_south, Y, 0, sink);
+    if (rc != HDP_OK) {
+      local_rc = rc;
+      local_msg = hdp_last_error();
+    }
   }
-  DevBuf dstat;
-  HDP_HIP_TRY(dstat.alloc(size_t(4) * (world + 1)));
   {
+    // status first: [world] gathered words followed by this rank's own word (allocated by hdp_comm_init_rank)
     const int32_t mine = local_rc;
-    HDP_HIP_TRY(hipMemcpyAsync(dstat.as<int32_t>() + world, &mine, 4, hipMemcpyHostToDevice, g_stream));
-    ncclResult_t r = ncclAllGather(dlocal.p, dgath.p, shard_bytes, ncclInt8, g_comm, g_stream);
-    if (r == ncclSuccess) r = ncclAllGather(dstat.as<int32_t>() + world, dstat.p, 4, ncclInt8, g_comm, g_stream);
-    if (r != ncclSuccess) return set_error(HDP_EHIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
-    if (wire_bytes) *wire_bytes = (int64_t)shard_bytes;
+    int32_t *dstat = g_comm_stat.as<int32_t>();
     std::vector<int32_t> stat(world);
-    HDP_HIP_TRY(hipMemcpyAsync(stat.data(), dstat.p, size_t(4) * world, hipMemcpyDeviceToHost, g_stream));
-    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+    hipError_t e = hipMemcpyAsync(dstat + world, &mine, 4, hipMemcpyHostToDevice, g_stream);
+    ncclResult_t r = e == hipSuccess ? ncclAllGather(dstat + world, dstat, 4, ncclInt8, g_comm, g_stream) : ncclSuccess;
+    if (e == hipSuccess && r == ncclSuccess)
+      e = hipMemcpyAsync(stat.data(), dstat, size_t(4) * world, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(g_stream);
+    if (r != ncclSuccess) return set_error(HDP_EHIP, "status ncclAllGather failed: %s", ncclGetErrorString(r));
+    if (e != hipSuccess) return set_error(HDP_EHIP, "status exchange failed: %s", hipGetErrorString(e));
     if (local_rc != HDP_OK) return set_error(local_rc, "%s", local_msg.c_str());
     for (int64_t r2 = 0; r2 < world; ++r2)
       if (stat[r2] != HDP_OK)
-        return set_error(HDP_EHIP, "the local metrics pass failed on rank %d (code %d)", (int)r2, (int)stat[r2]);
+        return set_error(HDP_EHIP, "the sharded metrics call failed on rank %d (code %d); no rank entered the data all-gather",
+                         (int)r2, (int)stat[r2]);
+    if (empty) return HDP_OK;
+    r = ncclAllGather(dlocal.p, dgath.p, shard_bytes, ncclInt8, g_comm, g_stream);
+    if (r != ncclSuccess) return set_error(HDP_EHIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
+    if (wire_bytes) *wire_bytes = (int64_t)shard_bytes;
+    HDP_HIP_TRY(hipStreamSynchronize(g_stream));
   }
   dlocal.release();
   // widen + regroup on the gathered buffer, slab by slab of (metric, percentile, definition) planes
@@ -852,6 +871,31 @@ int hdp_metrics_f32_planes_i64_sharded(const float *x, int64_t n_mem, int64_t n_
   return HDP_OK;
 }
 
+// Unit-level entry for the second half of the sharded call, without a communicator: `gathered` is what the data
+// all-gather of `world` ranks leaves on every rank -- [world][4 * P * D][Y][n_mem * shard] int16 (host), shard =
+// ceil(n_total / world), zero columns where a rank owns fewer cells -- and `out` receives the int64 planes of the whole
+// grid, [4][P][D][n_mem * n_total][Y], exactly as hdp_metrics_f32_planes_i64_sharded regroups them.  Lets a one-GPU test
+// pin the multi-rank layout (world > 1, a short last shard, several members).
+int hdp_metrics_planes_i64_regroup(const int16_t *gathered, int64_t world, int64_t n_mem, int64_t n_total, int64_t P,
+                                   int64_t D, int64_t Y, int64_t *out) {
+  HDP_REQUIRE(device_ready(), HDP_ENODEV, "hdp_init() has not selected a HIP device");
+  HDP_REQUIRE(world >= 1 && n_mem >= 1 && n_total >= 0 && P >= 1 && D >= 1 && Y >= 0, HDP_EINVAL, "bad sizes");
+  if (n_total == 0 || Y == 0) return HDP_OK;
+  HDP_REQUIRE(gathered && out, HDP_EINVAL, "NULL buffer");
+  const int64_t shard = (n_total + world - 1) / world, mpd = 4 * P * D, series = n_mem * n_total;
+  const size_t gbytes = size_t(world) * mpd * Y * n_mem * shard * 2, obytes = size_t(mpd) * series * Y * 8;
+  DevBuf dg, dp;
+  HDP_HIP_TRY(dg.alloc(gbytes));
+  HDP_HIP_TRY(dp.alloc(obytes));
+  HDP_HIP_TRY(hipMemcpyAsync(dg.p, gathered, gbytes, hipMemcpyHostToDevice, g_stream));
+  const int rc = launch_metrics_planes_i64_gathered(dg.as<int16_t>(), mpd, Y, world, shard, n_mem, n_total, 0, mpd,
+                                                    dp.as<int64_t>(), g_stream);
+  if (rc != HDP_OK) return rc;
+  HDP_HIP_TRY(hipMemcpyAsync(out, dp.p, obytes, hipMemcpyDeviceToHost, g_stream));
+  HDP_HIP_TRY(hipStreamSynchronize(g_stream));
+  return HDP_OK;
+}
+
 const char *hdp_metrics_plan_describe(const hdp_metrics_plan *plan) {
   static thread_local char buf[256];
   if (!plan) return "";
@@ -868,7 +912,7 @@ const char *hdp_metrics_plan_describe(const hdp_metrics_plan *plan) {
              "consecutive batches overlap on the plan's streams)",
              hdp::metrics_year_words(plan) ? "exceed_years_kernel" : (plan->opt_pairs ? "exceed_pairs_kernel" : "exceed_kernel"),
              (plan->defs_fit16 && plan->T <= 65535 && plan->opt_packed)
-                 ? (plan->opt_queue ? "16q (packed 16-bit state, lane-private run queues)" : "16 (packed 16-bit state)") : "");
+                 ? "16 (packed 16-bit state)" : "");
   return buf;
 }
 
@@ -923,14 +967,31 @@ int hdp_comm_init_rank(const void *id_bytes, int rank, int world) {
   }
   g_comm_rank = rank;
   g_comm_world = world;
+  const hipError_t e = g_comm_stat.alloc(size_t(4) * (world + 1));
+  if (e != hipSuccess) {
+    (void)ncclCommDestroy(g_comm);
+    g_comm = nullptr;
+    g_comm_rank = -1;
+    g_comm_world = 0;
+    return set_error(HDP_ENOMEM, "allocating the communicator's status words failed: %s", hipGetErrorString(e));
+  }
   return HDP_OK;
 }
 
 int hdp_comm_destroy(void) {
   if (g_comm) (void)ncclCommDestroy(g_comm);
+  g_comm_stat.release();
   g_comm = nullptr;
   g_comm_rank = -1;
   g_comm_world = 0;
+  return HDP_OK;
+}
+
+// RCCL's version code (ncclGetVersion), e.g. 22105: which librccl a process mapped is part of a multi-GPU diagnosis
+int hdp_rccl_version(int *version) {
+  HDP_REQUIRE(version, HDP_EINVAL, "NULL version");
+  const ncclResult_t r = ncclGetVersion(version);
+  if (r != ncclSuccess) return set_error(HDP_EHIP, "ncclGetVersion failed: %s", ncclGetErrorString(r));
   return HDP_OK;
 }
 

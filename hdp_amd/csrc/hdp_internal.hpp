@@ -166,7 +166,7 @@ struct hdp_metrics_plan {
   // split path: the streaming exceedance kernel of batch b+1 runs on a second stream beside the
   // VALU-bound state-machine kernel of batch b (created on first use, owned by the plan)
   // HDP_METRICS_* selectors (testing and A/B only; every value gives the same results), read once at plan creation
-  int32_t opt_general = 0, opt_fused = 0, opt_cells = 1, opt_packed = 1, opt_overlap = 1, opt_pairs = 1, opt_cw = 0, opt_years = 1, opt_years_lds = 16384, opt_simple = 1, opt_queue = 0;
+  int32_t opt_general = 0, opt_fused = 0, opt_cells = 1, opt_packed = 1, opt_overlap = 1, opt_pairs = 1, opt_cw = 0, opt_years = 1, opt_years_lds = 16384, opt_simple = 1;
   int64_t opt_batch = 0;
   mutable hipStream_t aux_stream = nullptr, aux_stream2 = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_exceed[2] = {nullptr, nullptr}, ev_state[2] = {nullptr, nullptr};

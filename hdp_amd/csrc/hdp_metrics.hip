@@ -1270,288 +1270,6 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
-#ifdef HDP_PROTO_QUEUE
-// ---- the packed kernel with per-lane pace between season closings (round 3 prototype) -------------------------------
-// MEASURED AND NOT ADOPTED (profiles/r03_metrics_queue*): 13.1 ms against the lock-step kernel's 9.4 ms per 65 536 series
-// at 32 queue entries per lane, 15.2 at 48, 21.8 at 64.  PMC: 2.31e9 vector instructions per launch against 1.87e9 --
-// phase A costs ~45 vector + ~30 scalar instructions a trip once it is a loop of its own (three nested exec-mask regions),
-// phase B ~90, so a mean run costs 45 x 2.0 + 90 x 1.5 = 225 against the fused trip's 97 x 2.0 = 194 -- and the queues
-// (8 KB per wave at 32 entries) cut the resident waves from 20 to 12 per CU.  Built only with -DHDP_PROTO_QUEUE
-// (`make EXTRA=-DHDP_PROTO_QUEUE`), selected with HDP_METRICS_QUEUE=32|48|64; tests/test_round3_gpu.py runs it when built.
-// metrics_kernel_cells16 walks a word's runs in lock step: a trip of its inner loop extracts ONE run per lane and steps every
-// definition's state machine with it, so a word costs (the maximum over the 64 series of the runs in that word) trips of
-// ~116 vector instructions -- 1.85x the mean lane's runs on the bench's exceedance words.  Here the two halves of a trip
-// are separated by a lane-private queue in LDS:
-//   phase A (still per word, lock step, ~35 instructions a trip): extract the runs that can matter and push (start, end)
-//            onto the lane's queue.  Which runs matter no longer depends on the state machines: a run is KEPT when it is at
-//            least min over definitions of max(min_duration, 1) days long, or starts within max over definitions of
-//            max_break days of the end of the previous kept run.  Every other run is a no-op for every definition: the
-//            gap before it has ended every heatwave (gap > every max_break), it is shorter than every min_duration, so
-//            the reference's first branch (metric.py:44-47) leaves hw, subs and id alone; and the gap the next kept run
-//            sees, measured from the previous KEPT run, is longer still, so it clears the same heatwaves.
-//   phase B (per lane pace, ~80 instructions a trip): every lane drains ITS queue through the state machines; a trip is one
-//            queued run of every lane that still has one, so the trips of a drain are the maximum over the lanes of the runs
-//            queued since the last drain -- a year's worth, whose maximum is 1.39x its mean -- not a sum of per-word maxima.
-// Drains happen where the lock step is unavoidable anyway: before a season is closed (seasons are wave-uniform, their sums
-// are stored by all lanes at once), when a lane's queue is full, and at the end of the record.
-template <int NP, int NS, int CAP>  // as metrics_kernel_cells16; CAP queue entries per lane
-__global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(HDP_C16_WAVES))) void metrics_kernel_cells16q(
-    MetDev md, const uint8_t *__restrict__ is_south, int64_t n_cells, int16_t *__restrict__ out, int d0) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t n_grp = (n_cells + 63) >> 6;
-  const int64_t task = int64_t(blockIdx.x) * kMetWaves + wave;  // (64 series, percentile); definitions [d0, d0 + DG)
-  if (task >= n_grp * md.P) return;  // no workgroup barriers in this kernel
-  const int p = int(task % md.P);
-  const int64_t cell = (task / md.P) * 64 + lane;
-  const bool valid = cell < n_cells;
-  const int my_hemi = valid ? int(is_south[cell]) : 2;
-  const unsigned long long *brow = md.bits_g + ((valid ? cell : 0) * md.P + p) * int64_t(md.words_pad);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *slot = smem + (size_t(wave) * 64 + lane) * kSlotPitch;
-  uint4 *slot4 = reinterpret_cast<uint4 *>(slot);
-  const unsigned long long *slot8 = reinterpret_cast<const unsigned long long *>(slot);
-  // queue: entry i of lane l at word i * 64 + l of the wave's block -- conflict-free whatever the lanes' fill levels
-  uint32_t *queue = reinterpret_cast<uint32_t *>(smem + size_t(kMetWaves) * 64 * kSlotPitch) + size_t(wave) * CAP * 64 + lane;
-
-  uint32_t min_dur[NP], max_break[NP], max_subs[NP];
-  int mmin = 0x7fffffff, bmax = 0;
-#pragma unroll
-  for (int k = 0; k < NP; ++k) {
-    uint32_t a = 0, b = 0, c = 0;
-#pragma unroll
-    for (int hlf = 0; hlf < 2; ++hlf) {
-      const int d = d0 + 2 * k + hlf;
-      const bool real = d < md.D;
-      const int md_ = real ? md.defs[d * 3 + 0] : 32767;
-      const int mb_ = real ? md.defs[d * 3 + 1] : 0;
-      const int ms_ = real ? min(md.defs[d * 3 + 2], 32767) : 0;
-      a |= uint32_t(md_) << (16 * hlf);
-      b |= uint32_t(mb_) << (16 * hlf);
-      c |= uint32_t(max(ms_, 0)) << (16 * hlf);
-      if (real) mmin = min(mmin, max(md_, 1));
-      if (real) bmax = max(bmax, mb_);
-    }
-    min_dur[k] = a; max_break[k] = b; max_subs[k] = c;
-  }
-  const int skip = min(mmin, 64);  // look-ahead of the long-run mask is one 64-day word
-  const int Y = md.Y, dmax = md.dmax;
-  const int n_words = md.n_words;
-  const int len5 = md.year_words ? md.n_doy - 64 * (kYearSpans - 1) : 64;
-  const int64_t n_total = md.out_cells;
-  const int64_t plane = int64_t(Y) * n_total;
-
-  for (int h = 0; h < 2; ++h) {  // lanes of one hemisphere at a time: season bounds stay wave-uniform
-    const bool act = my_hemi == h;
-    if (__ballot(act) == 0) continue;
-    const int2 *seas = md.seasons + (h ? Y : 0);
-    int si = 0;
-    int sa = 0x7fffffff - 1024, sb = 0x7fffffff - 1024;
-    if (Y > 0) {
-      sa = __builtin_amdgcn_readfirstlane(seas[0].x);
-      sb = __builtin_amdgcn_readfirstlane(seas[0].y);
-    }
-    CPair st[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) st[k] = CPair{0, 0, 0, 0, 0, 0, 0, 0};
-    int open = 0, s_open = 0;
-    int e_prev = -(1 << 30);  // phase B: end of the last run the state machines saw
-    int e_kept = -(1 << 30);  // phase A: end of the last run queued
-
-    auto credit_k = [&](CPair &c, uint32_t lab, uint32_t run_id, int days) {
-      const uint32_t dd = pk_dup(days) & lab;
-      const uint32_t first = lab & pk_nz(run_id ^ c.last_id);
-      c.hwf = pk_add(c.hwf, dd);
-      c.hwn = pk_sub(c.hwn, first);  // first is -1 per half: += 1
-      c.cur = pk_add(c.cur & ~first, dd);
-      c.last_id = bsel(lab, run_id, c.last_id);
-      c.hwd = pk_max(c.hwd, c.cur);
-    };
-    // one queued run [s, e): the gap before it, the reference state machine, the season credit -- every definition
-    auto run_step = [&](int s, int e) {
-      const uint32_t gap = pk_dup(min(s - e_prev, 32767));  // >= 1
-      const uint32_t len = pk_dup(min(e - s, 32767));
-      const int days = min(e, sb) - max(s, sa);
-      e_prev = e;
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        CPair &c = st[k];
-        const uint32_t ge = ~pk_lt(len, min_dur[k]);
-        if (k < NS) {  // hw, subs, id, cur, last_id of such a pair are never touched (hw stays 0)
-          if (days > 0) {
-            const uint32_t dd = pk_dup(days) & ge;
-            c.hwf = pk_add(c.hwf, dd);
-            c.hwn = pk_sub(c.hwn, ge);  // ge is -1 per half: += 1
-            c.hwd = pk_max(c.hwd, dd);
-          }
-          continue;
-        }
-        const uint32_t hw = c.hw & ~pk_lt(max_break[k], gap);  // metric.py:48-49
-        const uint32_t sub = hw & pk_lt(c.subs, max_subs[k]);
-        const uint32_t label = sub | ge;
-        c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), c.subs & ~hw);
-        c.id = pk_sub(c.id, ge & ~sub);  // += 1 where a new heatwave starts
-        c.hw = label;
-        if (days > 0) credit_k(c, label, c.id, days);
-      }
-    };
-    // close season si (wave-uniform) for every lane and definition; the queue is empty here
-    auto finalize = [&](bool credit_open) {
-      const bool pre = credit_open && open && s_open < sb;
-      const int pre_days = sb - max(s_open, sa);
-      const uint32_t gap_open = pk_dup(min(s_open - e_prev, 32767));  // the open run has not met the state machines yet
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        CPair &c = st[k];
-        if (pre && k < NS) {
-          const uint32_t dd = pk_dup(pre_days);
-          c.hwf = pk_add(c.hwf, dd);
-          c.hwn = pk_add(c.hwn, 0x00010001u);
-          c.hwd = pk_max(c.hwd, dd);
-        } else if (pre) {
-          // a run still open dmax days past the season's end is labelled in every branch of the reference
-          const uint32_t hw = c.hw & ~pk_lt(max_break[k], gap_open);
-          const uint32_t sub = hw & pk_lt(c.subs, max_subs[k]);
-          credit_k(c, 0xffffffffu, pk_sub(c.id, ~sub), pre_days);  // id + 1 unless it continues as a sub-event
-        }
-#pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-          const int d = d0 + 2 * k + hlf;
-          if (act && d < md.D) {
-            const unsigned hwf = (c.hwf >> (16 * hlf)) & 0xffffu, hwn = (c.hwn >> (16 * hlf)) & 0xffffu;
-            const unsigned hwd = (c.hwd >> (16 * hlf)) & 0xffffu;
-            const unsigned hwa = hwn ? hwf / hwn : 0u;  // == HWF // HWN
-            const int dout = md.def_perm ? md.def_perm[d] : d;
-            int16_t *o = out + ((int64_t(p) * md.D + dout) * Y + si) * n_total + md.cell_off + cell;
-            const int64_t mstride = int64_t(md.P) * md.D * plane;
-            o[0] = (int16_t)hwf;
-            o[mstride] = (int16_t)hwn;
-            o[2 * mstride] = (int16_t)hwd;
-            o[3 * mstride] = (int16_t)hwa;
-          }
-        }
-        c.hwf = c.hwn = c.hwd = c.cur = 0;
-        c.last_id = 0;
-      }
-      si += 1;
-      if (si < Y) {
-        sa = __builtin_amdgcn_readfirstlane(seas[si].x);
-        sb = __builtin_amdgcn_readfirstlane(seas[si].y);
-      } else {
-        sa = sb = 0x7fffffff - 1024;
-      }
-    };
-
-    const uint4 *bline = reinterpret_cast<const uint4 *>(brow);
-    uint4 pf[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) pf[q] = act ? bline[q] : make_uint4(0, 0, 0, 0);
-    int w = 0, t0 = 0, jy = 0;  // phase A's cursor: word w starts on day t0, is word jy of its year
-    int nq = 0;                 // runs on this lane's queue
-    int pos = 0;                // scan position inside word w (kept across a drain in mid-word)
-    bool in_word = false;
-    while (true) {
-      // ---------------- phase A: queue runs until a season must be closed, a queue is full, or the record ends
-      bool boundary = false, full_any = false;
-      while (w < n_words) {
-        const bool short_word = md.year_words && jy == kYearSpans - 1;
-        const int L = short_word ? len5 : 64;
-        if (!in_word) {
-          if (si < Y && sb + dmax <= t0) {  // wave-uniform: season si closes before this word is looked at
-            boundary = true;
-            break;
-          }
-          if ((w & 7) == 0) {  // wave-uniform: park the fetched block, request the next one
-#pragma unroll
-            for (int q = 0; q < 4; ++q) slot4[q] = pf[q];
-            const bool more = act && (w + 8 < md.words_pad);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pf[q] = more ? bline[(w >> 1) + 4 + q] : make_uint4(0, 0, 0, 0);
-          }
-          pos = 0;
-          in_word = true;
-        }
-        const unsigned long long vmask = ~0ull >> (64 - L);
-        const unsigned long long word = slot8[w & 7];
-        // the day after bit 63 of a short word is bit 64 - L of the next word (bits L.. repeat its first 64 - L bits)
-        const unsigned long long nxt =
-            ((w & 7) != 7 ? slot8[(w & 7) + 1] : (((unsigned long long)pf[0].y << 32) | pf[0].x)) >> (64 - L);
-        unsigned long long longs = word;
-        for (int k = 1; k < skip; ++k) longs &= (word >> k) | (nxt << (64 - k));
-        longs &= vmask;                                   // runs of >= skip days that START in this word
-        const unsigned long long starts = word & vmask;   // hot days at positions of this word
-        const unsigned long long ends = ~word & vmask;    // cool days at positions of this word
-        // nothing of this word can be kept when no run is open, none is long and the word starts too far behind the
-        // last kept run for its first run (and so for every later one) to be near it
-        const bool near0 = (t0 + pos - e_kept) <= bmax;
-        const bool work = open ? (ends != 0ull) : ((near0 ? starts : longs) >> pos) != 0ull;
-        bool full = false;
-        if (__ballot(work) != 0) {
-          while (true) {
-            if (!open) {
-              const unsigned long long r_any = starts >> pos;
-              const int p_any = pos + __builtin_ctzll(r_any | (1ull << 63));
-              const bool near = (r_any != 0ull) && (t0 + p_any - e_kept) <= bmax;
-              const unsigned long long r = near ? r_any : (longs >> pos);
-              if (r == 0) break;
-              pos += __builtin_ctzll(r);
-              s_open = t0 + pos;
-              open = 1;
-            }
-            const unsigned long long rz = ends >> pos;
-            if (rz == 0) break;  // the run continues into the next word
-            pos += __builtin_ctzll(rz);
-            const int e = t0 + pos;
-            open = 0;
-            queue[nq * 64] = uint32_t(s_open) | (uint32_t(e) << 16);
-            nq += 1;
-            e_kept = e;
-            if (nq == CAP) {
-              full = true;
-              break;
-            }
-          }
-        }
-        if (__ballot(full) != 0) {  // drain, then come back to this word at `pos`
-          full_any = true;
-          break;
-        }
-        in_word = false;
-        w += 1;
-        t0 += L;
-        jy = (jy == kYearSpans - 1) ? 0 : jy + 1;
-      }
-      const bool at_end = !boundary && !full_any;
-      if (at_end && open) {  // a run reaching the end of the record closes at T (metric.py:27: zero padding)
-        // nq < CAP here: a queue that filled up set full_any, and this is not such a pass
-        queue[nq * 64] = uint32_t(s_open) | (uint32_t(md.T) << 16);
-        nq += 1;
-        open = 0;
-      }
-      // ---------------- phase B: every lane drains its queue at its own pace
-      {
-        uint32_t ent = (nq > 0) ? queue[0] : 0u;
-        for (int i = 0;; ++i) {
-          const bool has = i < nq;
-          if (__ballot(has) == 0) break;
-          const uint32_t cur = ent;
-          ent = (i + 1 < nq) ? queue[(i + 1) * 64] : 0u;  // next entry in flight behind this trip's arithmetic
-          if (has) run_step(int(cur & 0xffffu), int(cur >> 16));
-        }
-        nq = 0;
-      }
-      if (boundary) {
-        while (si < Y && sb + dmax <= t0) finalize(true);  // wave-uniform
-        continue;
-      }
-      if (full_any) continue;
-      break;
-    }
-    while (si < Y) finalize(false);
-  }
-}
-
-#endif  // HDP_PROTO_QUEUE
 
 // Row layout of the (percentile, definition)-per-lane kernels, [planes][nc][Ypitch], -> device layout
 // [planes][Y][n_total] at series offset cell_off.  One workgroup per (plane, 64 series), through LDS.
@@ -2395,27 +2113,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
                  plan->defs16_host[3 * (d0 + 2 * ns) + 1] == 0 &&
                  (d0 + 2 * ns + 1 >= md.D || plan->defs16_host[3 * (d0 + 2 * ns + 1) + 1] == 0))
             ++ns;
-#ifdef HDP_PROTO_QUEUE
-          const int qcap = plan->opt_queue;  // > 0: per-lane pace between season closings (metrics_kernel_cells16q)
-          const size_t lds_q = lds_c + size_t(kMetWaves) * 64 * 4 * size_t(qcap > 0 ? qcap : 0);
-#define HDP_C16_CASE(NPV, NSV)                                                                                              \
-  do {                                                                                                                      \
-    if (qcap >= 64) {                                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(metrics_kernel_cells16q<NPV, NSV, 64>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);                                      \
-      hipLaunchKernelGGL((metrics_kernel_cells16q<NPV, NSV, 64>), g16, t, lds_q, sm, mb, is_south_dev + c0, nc, out_dev, d0); \
-    } else if (qcap >= 48) {                                                                                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(metrics_kernel_cells16q<NPV, NSV, 48>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);                                      \
-      hipLaunchKernelGGL((metrics_kernel_cells16q<NPV, NSV, 48>), g16, t, lds_q, sm, mb, is_south_dev + c0, nc, out_dev, d0); \
-    } else if (qcap > 0)                                                                                                    \
-      hipLaunchKernelGGL((metrics_kernel_cells16q<NPV, NSV, 32>), g16, t, lds_q, sm, mb, is_south_dev + c0, nc, out_dev, d0); \
-    else                                                                                                                    \
-      hipLaunchKernelGGL((metrics_kernel_cells16<NPV, NSV>), g16, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev, d0);    \
-  } while (0)
-#else
 #define HDP_C16_CASE(NPV, NSV) hipLaunchKernelGGL((metrics_kernel_cells16<NPV, NSV>), g16, t, lds_c, sm, mb, is_south_dev + c0, nc, out_dev, d0)
-#endif
           switch (dg * 4 + ns) {
             case 2 * 4 + 0: HDP_C16_CASE(1, 0); break;
             case 2 * 4 + 1: HDP_C16_CASE(1, 1); break;

@@ -2266,6 +2266,9 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   }
   const ThrVariant var = thr_variant(plan, pd.debug);
   pd.select = var.select;
+  // hdp_threshold_plan_reserve walks this path with sentinel pointers: only the lane kernel's launcher owns scratch (and
+  // checks g_reserve_only); any other variant -- e.g. a debug build that turned the lane kernel off -- has nothing to reserve
+  if (g_reserve_only && !var.lane) return HDP_OK;
   if (var.lane) {
     pd.n_merge = plan->lane_n_merge;
     pd.dual = plan->lane_dual ? 1 : 0;

@@ -231,6 +231,15 @@ int hdp_metrics_f32_planes_i64_sharded(const float *x, int64_t n_mem, int64_t n_
                                        const int64_t *north, const int64_t *south,
                                        const uint8_t *is_south, int64_t Y, int64_t n_total,
                                        int64_t *out, int64_t *wire_bytes);
+/* A rank that fails before the data collective (bad arguments, an n_loc that is not its share, the shard or gathered
+ * buffer's allocation, its local pass) still meets the others in a 4-byte status all-gather, and every rank then returns
+ * an error without entering the data all-gather: no rank is left blocked in it. */
+
+/* The regrouping half of the sharded call on a host-supplied gathered buffer (no communicator): gathered
+ * [world][4 * P * D][Y][n_mem * shard] int16, shard = ceil(n_total / world), zero columns past a rank's cells ->
+ * out [4][P][D][n_mem * n_total][Y] int64.  Unit-level: pins the multi-rank layout on one GPU. */
+int hdp_metrics_planes_i64_regroup(const int16_t *gathered, int64_t world, int64_t n_mem, int64_t n_total,
+                                   int64_t P, int64_t D, int64_t Y, int64_t *out);
 
 /* ---- unit-level mirrors of the njit helpers (for the known-answer tests) ---- */
 
@@ -282,6 +291,7 @@ int hdp_weighted_mean_f64(const double *v, int64_t n_rows, int64_t n, const doub
 int hdp_comm_unique_id(void *id_out);
 int hdp_comm_init_rank(const void *id, int rank, int world);
 int hdp_comm_destroy(void);
+int hdp_rccl_version(int *version); /* ncclGetVersion of the librccl this process mapped (no communicator needed) */
 int hdp_comm_rank(void);   /* -1 without a communicator */
 int hdp_comm_world(void);  /* 0 without a communicator */
 int hdp_allgather_dev(const void *send_dev, size_t bytes_per_rank, void *recv_dev, void *stream);

@@ -27,3 +27,23 @@ def test_spawn_ranks_sets_the_rank_environment_and_relays_the_worst_exit_code(tm
     assert len({s["env"]["MASTER_PORT"] for s in seen}) == 1 and seen[0]["env"]["MASTER_PORT"].isdigit()
     assert all(s["argv"] == ["7", "--gpus", "3"] for s in seen)
     assert bench.spawn_ranks(2, script=str(stub), argv=[str(tmp_path), "0"]) == 0
+
+
+def test_spawn_ranks_takes_the_other_ranks_down_when_one_fails(tmp_path, monkeypatch):
+    """One rank exits 5 at once while the others would sit in a rendezvous for minutes: the launcher must stop them and
+    come back promptly with a failure code."""
+    import time
+
+    import bench
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(
+        "import os, sys, time\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    sys.exit(5)\n"
+        "time.sleep(120)\n")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(3, script=str(stub), argv=[])
+    assert time.monotonic() - t0 < 30.0
+    assert rc != 0 and rc >= 5

@@ -163,11 +163,11 @@ def test_c5_ensemble_4096_cells_properties_and_oracle_sample():
     assert np.array_equal(met_g, met_c)
 
 
-# ---- metrics_kernel_cells16q: per-lane pace between season closings (lane-private run queues in LDS) ----------------
+# ---- the lock-step state machines on the cases written for the round-3 run-queue prototype (the prototype itself was
+# measured slower -- profiles/r03_metrics_queue* -- and is no longer in the tree) -------------------------------------
 from tests.test_round2_gpu import _regular_case  # noqa: E402
 
 
-@pytest.mark.parametrize("cap", [32, 48, 64])
 @pytest.mark.parametrize("n_doy,T,P,defs", [
     (365, 365 * 9, 10, [[3, 0, 0], [3, 1, 1], [4, 0, 0], [4, 1, 1], [5, 0, 0], [5, 1, 1]]),
     (365, 365 * 40 + 17, 10, [[3, 0, 0], [3, 1, 1], [5, 2, 2]]),
@@ -177,25 +177,20 @@ from tests.test_round2_gpu import _regular_case  # noqa: E402
     (365, 365 * 12, 3, [[1, 0, 0], [0, 3, 1], [2, 5, 0], [1, 1, 3]]),      # min_duration 0/1: every run is kept; long breaks
     (365, 365 * 30, 2, [[3, 40, 2], [6, 2, 0], [2, 0, 0]]),               # a 40-day max_break keeps far-apart short runs
 ])
-def test_queued_state_machines_match_the_oracle_and_the_lock_step_kernel(cap, n_doy, T, P, defs, monkeypatch):
+def test_state_machines_match_the_oracle_on_year_aligned_and_day_aligned_words(n_doy, T, P, defs, monkeypatch):
     monkeypatch.setenv("HDP_METRICS_YEARS", "2")
     case = _regular_case(7000 + n_doy + P + len(defs), n_doy, T, 70, P, defs, long_runs=True)
     x, thr, doy_map, dfs, north, south, is_south = case
     want = c_oracle.metrics(x, thr, doy_map, dfs, north, south, is_south)
     lock = core.compute_heatwave_metrics(*case)
     assert np.array_equal(lock.astype(np.int64), want)
-    monkeypatch.setenv("HDP_METRICS_QUEUE", str(cap))
-    if "cells16q" not in core.MetricsPlan(doy_map, n_doy, dfs, north, south, P).describe():
-        pytest.skip("prototype kernel not in this build (make EXTRA=-DHDP_PROTO_QUEUE)")
-    got = core.compute_heatwave_metrics(*case)
-    assert np.array_equal(got, lock), (cap, n_doy, T, P, defs)
     monkeypatch.setenv("HDP_METRICS_YEARS", "0")      # day-aligned words (any calendar) through the same kernel
     assert np.array_equal(core.compute_heatwave_metrics(*case), lock)
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_queued_state_machines_random_sweep(seed, monkeypatch):
-    """Dense exceedance (queues fill up inside a year and inside a word), random definitions incl. large max_break."""
+def test_state_machines_random_sweep_dense_exceedance(seed, monkeypatch):
+    """Dense exceedance (many runs inside a year and inside a word), random definitions incl. large max_break."""
     rng = np.random.default_rng(12000 + seed)
     n_doy = int(rng.choice([365, 365, 360, 366, int(rng.integers(321, 385))]))
     years = int(rng.choice([3, 9, 26, 40]))
@@ -211,12 +206,8 @@ def test_queued_state_machines_random_sweep(seed, monkeypatch):
         pytest.skip("no complete season in this record")
     want = c_oracle.metrics(x, thr, doy_map, dfs, north, south, is_south)
     monkeypatch.setenv("HDP_METRICS_YEARS", "2")
-    for cap in (32, 64):
-        monkeypatch.setenv("HDP_METRICS_QUEUE", str(cap))
-        if "cells16q" not in core.MetricsPlan(doy_map, n_doy, dfs, north, south, P).describe():
-            pytest.skip("prototype kernel not in this build (make EXTRA=-DHDP_PROTO_QUEUE)")
-        got = core.compute_heatwave_metrics(*case)
-        assert np.array_equal(got.astype(np.int64), want), (cap, n_doy, T, P, defs)
+    got = core.compute_heatwave_metrics(*case)
+    assert np.array_equal(got.astype(np.int64), want), (n_doy, T, P, defs)
 
 
 def test_threshold_plan_reserve_then_launch():

@@ -1,0 +1,73 @@
+"""Round-4 GPU tests (through the C ABI):
+
+* the multi-rank layout of the sharded metrics call, pinned on one GPU: a gathered buffer built on the host from the
+  per-rank device layouts of a 3-rank split (a grid that does not divide by the world, three members) goes through
+  the regrouping kernel and must equal the unsharded planes;
+* a rank that fails before the data collective (allocation, its share of the grid, its own preparation) returns an
+  error through the status exchange and leaves the communicator usable.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from hdp_amd import _lib, core  # noqa: E402
+from hdp_amd import dist as hdist  # noqa: E402
+from tests.test_round3_gpu import _small_case  # noqa: E402
+
+
+@pytest.mark.parametrize("world,n_cells,members", [(3, 7, 3), (4, 6, 2), (2, 37, 1), (5, 3, 2)])
+def test_regroup_of_a_multi_rank_gathered_buffer(world, n_cells, members):
+    x, thr, dm, defs, north, south, hemi, members, n_cells = _small_case(seed=11, n_cells=n_cells, members=members)
+    T = x.shape[1]
+    want = core.compute_heatwave_metric_planes(x, thr, dm, defs, north, south, hemi)      # [4, P, D, members * n, Y]
+    P, D, Y = want.shape[1], want.shape[2], want.shape[4]
+    shard = hdist.shard_size(n_cells, world)
+    gathered = np.zeros((world, 4, P, D, Y, members * shard), dtype=np.int16)
+    x3, h2 = x.reshape(members, n_cells, T), hemi.reshape(members, n_cells)
+    for r in range(world):
+        lo, hi = hdist.shard_bounds(n_cells, world, r)
+        if hi == lo:
+            continue          # a rank without cells contributes zeros (small grids: the last ranks)
+        lay = core.compute_heatwave_metrics_layout(np.ascontiguousarray(x3[:, lo:hi]).reshape(-1, T), thr[lo:hi], dm, defs,
+                                                   north, south, np.ascontiguousarray(h2[:, lo:hi]).reshape(-1))
+        for m in range(members):   # member m's cells at columns m * shard + c of the rank's padded shard buffer
+            gathered[r, ..., m * shard: m * shard + (hi - lo)] = lay[..., m * (hi - lo): (m + 1) * (hi - lo)]
+    got = core.regroup_gathered_planes(gathered, world, members, n_cells)
+    assert got.dtype == np.int64 and got.shape == want.shape
+    assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        core.regroup_gathered_planes(gathered[:, :, :, :, :, :-1], world, members, n_cells)
+
+
+def test_a_failing_rank_reports_through_the_status_exchange():
+    x, thr, dm, defs, north, south, hemi, members, n_cells = _small_case(seed=7)
+    planes = core.compute_heatwave_metric_planes(x, thr, dm, defs, north, south, hemi)
+    hdist.comm_init_rank(hdist.comm_unique_id(), 0, 1)
+    try:
+        os.environ["HDP_FAULT_INJECT"] = "sharded_alloc"      # the gathered buffer's allocation "fails"
+        try:
+            with pytest.raises(_lib.HdpError) as ei:
+                core.compute_heatwave_metric_planes_sharded(x, thr, dm, defs, north, south, hemi, members, n_cells)
+            assert ei.value.code == -4 and "gathered" in str(ei.value)
+        finally:
+            del os.environ["HDP_FAULT_INJECT"]
+        with pytest.raises(_lib.HdpError) as ei:               # not this rank's share of the grid
+            core.compute_heatwave_metric_planes_sharded(x, thr, dm, defs, north, south, hemi, members, n_cells + 1)
+        assert "owns" in str(ei.value)
+        with pytest.raises(ValueError):                        # the rank's own preparation fails (tables do not fit)
+            core.compute_heatwave_metric_planes_sharded(x, thr, dm[:-1], defs, north, south, hemi, members, n_cells)
+        # the communicator and the entry point are still good afterwards
+        got, wire = core.compute_heatwave_metric_planes_sharded(x, thr, dm, defs, north, south, hemi, members, n_cells)
+        assert np.array_equal(got, planes) and wire == planes.size * 2
+    finally:
+        hdist.comm_destroy()
+
+
+def test_rccl_version_and_mapped_runtime_are_reported():
+    info = _lib.runtime_report()
+    assert info["rccl_version"] > 20000
+    for key in ("librccl", "libamdhip64", "libhsa-runtime64"):
+        assert info["mapped"][key], info
