@@ -903,21 +903,33 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
   double2 h12;      // popped group's 2nd and 3rd head
   double h3;        // ... and 4th
   uint32_t lo_cur;  // payload of the popped head
-  uint32_t g_cur;
+  uint32_t aA, aB;  // absolute LDS addresses of the popped group's strips: computed for the reads, reused by the write-back
+  const uint32_t sA0 = uint32_t(reinterpret_cast<uintptr_t>(sA)), sB0 = uint32_t(reinterpret_cast<uintptr_t>(sB));
+  typedef double v2f64 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v2f64 *lds_d2;
+  typedef __attribute__((address_space(3))) double *lds_d1;
   auto issue = [&](double top) {
     lo_cur = uint32_t(__double2loint(top));
-    g_cur = lo_cur & 3u;
+    const uint32_t g = lo_cur & 3u;
+    aB = __umul24(g, uint32_t(ROWS * 8)) + sB0;
+    aA = __umul24(g, uint32_t(ROWS * 16)) + sA0;
     nk = lds_u32((lo_cur & 0x3fffcu) + (TOP ? 4u : uint32_t(-4)));  // payloads hold absolute LDS addresses
-    h12 = *reinterpret_cast<const double2 *>(sA + g_cur * (ROWS * 16));
-    h3 = *reinterpret_cast<const double *>(sB + g_cur * (ROWS * 8));
+    {
+      const v2f64 t = *reinterpret_cast<lds_d2>(uintptr_t(aA));
+      h12 = make_double2(t.x, t.y);
+    }
+    h3 = *reinterpret_cast<lds_d1>(uintptr_t(aB));
   };
-  double b1 = 0.0, b2 = 0.0, b3 = 0.0;  // previous step's group after insertion (what its write-back stores)
-  uint32_t g_prev = 4;
   issue(m[0]);
+  // One step (round 4: written back BEFORE the next step's reads are issued).  Rounds 2-3 issued the next step's reads
+  // first and finished the group in their shadow, which needs a bypass when two consecutive steps pop from the same
+  // group (the strip's write-back is still behind the read): one compare, six selects and a move per step.  The kernel
+  // turned out to be bound as much by the instructions it issues as by the chain's latency (PMC round 4: one vector
+  // instruction per 5.8 SIMD-cycles), and without the bypass a step is 8 instructions shorter at the price of 6 more on the
+  // dependent chain: 14.46 -> 13.73 ms per 131 072 cells.  A wave's LDS operations execute in order, so the reads see the
+  // write-back.  `prev` (the order statistic before the current one) is only read by an emission: it is captured by the
+  // caller before the last step of a stretch, not in every step.
   auto do_step = [&]() {
-    prev = m[0];
-    const uint32_t g = g_cur;
-    const bool same = g == g_prev;
     uint32_t pay = lo_cur + (TOP ? 4u : uint32_t(-4));
     if constexpr (TOP && TIER) {
       // Tiered image: slot tier_k + 1 of a column holds the marker 0x7ff00000 | column (a NaN pattern no sample has;
@@ -943,22 +955,19 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
       }
     }
     const double fresh = head(nk, pay);
-    const double h1 = same ? b1 : h12.x;
-    const double t0 = better(fresh, h1);  // the group's new top
+    const double t0 = better(fresh, h12.x);  // the group's new top
+    const double w1 = worse(fresh, h12.x);
+    const double b1 = better(w1, h12.y);
+    const double w2 = worse(w1, h12.y);
+    const double b2 = better(w2, h3);
+    const double b3 = worse(w2, h3);
+    *reinterpret_cast<lds_d2>(uintptr_t(aA)) = v2f64{b1, b2};
+    *reinterpret_cast<lds_d1>(uintptr_t(aB)) = b3;
     double m0n = t0;
     if constexpr (NG >= 2) m0n = better(t0, m[1]);
-    const double h2 = same ? b2 : h12.y, h3v = same ? b3 : h3;
     __builtin_amdgcn_sched_barrier(0);
-    issue(m0n);  // next step's reads first
+    issue(m0n);  // the next step's reads go out before the cached tops are finished
     __builtin_amdgcn_sched_barrier(0);
-    const double w1 = worse(fresh, h1);
-    b1 = better(w1, h2);
-    const double w2 = worse(w1, h2);
-    b2 = better(w2, h3v);
-    b3 = worse(w2, h3v);
-    *reinterpret_cast<double2 *>(sA + g * (ROWS * 16)) = make_double2(b1, b2);
-    *reinterpret_cast<double *>(sB + g * (ROWS * 8)) = b3;
-    g_prev = g;
     m[0] = m0n;
     if constexpr (NG >= 2) {
       double w = worse(t0, m[1]);
@@ -974,7 +983,12 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
   int step = 0;
   while (true) {
     const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
-    for (; step < stop; ++step) do_step();
+    if (step < stop) {
+      for (; step < stop - 1; ++step) do_step();
+      prev = m[0];  // order statistic stop - 1: what an emission at `stop` pairs with
+      do_step();
+      ++step;
+    }
     if (step >= steps) break;
 #if defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 4)
     {  // ablation: no emission (timing only)
@@ -1041,6 +1055,9 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
 // When the intervals have closed, sum c_j = R and the R-th largest key is the best of the W heads
 // col_j[c_j + 1]; the (R + 1)-th is the runner-up of those heads and the winner's successor.
 // The adjacent pair (R, R + 1) is exactly what one interpolated quantile needs.
+#ifndef HDP_SELECT_WARM
+#define HDP_SELECT_WARM 1
+#endif
 template <int NC>
 __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, const uint32_t *flags, int row0,
                                             int nrows, int tid, int64_t cell, double *__restrict__ out) {
@@ -1073,6 +1090,13 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
     }
     if (nan_or >> 31) rf.n_pos = -1;
 
+    // Round 1 (round 4 of the build): instead of the middle key of the widest interval -- for R = 3000 of 15 000 that is
+    // key 500 of a column, rank ~7500: several rounds go by just homing in -- the pivot is the key the wanted element is
+    // EXPECTED to be near: position R / W of the window's centre column (the centre day of the window is the most typical
+    // of its columns).  And after every count the distance |R - G| bounds every column's remaining move (no column can
+    // add or give back more keys than the pivot's rank missed by), so the intervals collapse to that width at once:
+    // 6.5 - 10 rounds and 34 - 50 stride trips per lane instead of 12 - 14 and 62 - 75 (bench generator, S = 1000).
+    bool first = HDP_SELECT_WARM != 0;
     while (true) {
       // widest interval -> pivot (its middle key: the pivot's own interval at least halves every round)
       int wj = 0, ww = hi[0] - lo[0], wlo = lo[0], wbase = base[0];
@@ -1086,7 +1110,15 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
         wbase = better ? base[j] : wbase;
       }
       if (ww <= 0) break;
-      const int mid = wlo + ((ww + 1) >> 1);  // in [lo + 1, hi]
+      int mid = wlo + ((ww + 1) >> 1);  // in [lo + 1, hi]
+      if (first) {  // every interval is still [0, min(S, R)]: any column may supply the pivot
+        const int wc = (W - 1) >> 1;  // centre of the row's column list
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          if (j == wc) { wj = j; wbase = base[j]; }
+        mid = min(max((R + (W >> 1)) / W, 1), ww);
+        first = false;
+      }
       const int pkey = colk[wbase + mid];
       // Per column: c_j = number of keys ranked above the pivot.  lo_j <= c_j <= hi_j is known, so a
       // descent in power-of-two strides from lo_j finds it without looking at hi_j: key > thr[j] is
@@ -1122,12 +1154,20 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
       if (G == R) {  // the pivot is the wanted element
 #pragma unroll
         for (int j = 0; j < NC; ++j) lo[j] = hi[j] = pos[j];
-      } else if (G > R) {  // pivot ranked below it: at most these many keys of each column are above it
+      } else if (G > R) {  // pivot ranked below it: at most these many keys of each column are above it ...
+        const int back = HDP_SELECT_WARM ? G - R : (1 << 30);  // ... and at most G - R fewer than above the pivot
 #pragma unroll
-        for (int j = 0; j < NC; ++j) hi[j] = pos[j];
+        for (int j = 0; j < NC; ++j) {
+          hi[j] = pos[j];
+          lo[j] = max(lo[j], pos[j] - back);
+        }
       } else {  // pivot ranked above it (so the pivot itself counts in its own column)
+        const int fwd = HDP_SELECT_WARM ? R - G - 1 : (1 << 30);  // keys still to be placed once the pivot is counted
 #pragma unroll
-        for (int j = 0; j < NC; ++j) lo[j] = pos[j] + ((j == wj) ? 1 : 0);
+        for (int j = 0; j < NC; ++j) {
+          lo[j] = pos[j] + ((j == wj) ? 1 : 0);
+          hi[j] = min(hi[j], lo[j] + fwd);
+        }
       }
     }
 
