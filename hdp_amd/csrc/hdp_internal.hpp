@@ -104,15 +104,8 @@ struct hdp_threshold_plan {
   hdp::DevBuf blk_sort_off, sort_slots;  // per block: the LDS column slots it loads and sorts
   // pipelined kernel (S <= 128): producer waves gather + sort the next block in registers while
   // the merging waves work on the current one
-  bool pipe = false;
   bool select_only = false;  // LDS sized without merge heads: only the rank-selection kernel can run this plan
-  int32_t lpc = 0;          // lanes per column of the register sort (1..16), 8 keys per lane
   int32_t n_merge = 0;      // waves that merge (ceil(rows_per_block / 64)); the rest produce
-  hdp::DevBuf tix;          // int32 [block columns][8 * lpc] time index of sample e of a column, -1 = none
-  hdp::DevBuf blk_col_off;  // int32 [n_blocks] first row of each block in tix
-  hdp::DevBuf ninf;         // four floats, -inf
-  bool vec = false;         // lpc == 16 and the block columns split into runs (>= 4) of adjacent time steps
-  hdp::DevBuf blk_grp_off, grp_col;  // vec: int32 [n_blocks + 1] offsets, first column of every group of four
   mutable hdp::DevBuf clk;       // HDP_THR_DEBUG=8 phase clocks (-DHDP_DEBUG_ABLATIONS builds only)
   // time-major input (hdp_thresholds_f32_tm_dev): two series-major staging chunks, a copy stream, fork/join events
   mutable hdp::DevBuf tm_stage;
@@ -139,7 +132,7 @@ struct hdp_threshold_plan {
   hdp::DevBuf blk_tixl_off;      // int32 [n_blocks] first element of each block in tixl
   // HDP_THR_* selectors (testing and A/B only; every value gives the same results): read ONCE, when the plan is
   // created, and kept here -- a launch never looks at the environment.  -1 / 0 = not set.
-  int32_t opt_pipe = -1, opt_vec = -1, opt_select = -1, opt_lane = -1;
+  int32_t opt_pipe = -1, opt_select = -1, opt_lane = -1;
   int64_t opt_grid = 0;
 };
 

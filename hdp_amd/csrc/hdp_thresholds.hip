@@ -43,16 +43,13 @@ struct ThrDev {
   const QuantileParam *qp;
   const int2 *tgt_top, *tgt_bot;
   const int32_t *blk_sort_off, *sort_slots;  // one-workgroup-per-cell kernel: LDS column slots a block (re)loads and sorts
-  const int32_t *tix, *blk_col_off;  // pipelined kernel: (block column, sample) -> time index
   const int32_t *tixl, *blk_tixl_off;  // lane-per-column kernel: per block [S][64 * tasks] byte offsets of the samples
   // lane-per-column kernel, tiered image: the top `tier_k` samples of a column live in LDS (column pitch `img_pitch`
   // words), samples tier_k.. in a per-workgroup global tail [parity][sample - tier_k][tail_pitch] (tier_k == S: all in LDS)
   int tier_k, img_pitch, tail_pitch;
   int dual;  // lane kernel, blocked form: the descending and the ascending walk of a row on two different merging waves
   float *tail;
-  const float *ninf;                 // four -inf words (what a slot without a sample loads)
-  const int32_t *blk_grp_off, *grp_col;  // 16-byte gathers: first column of every group of four, per block
-  int SL, n_merge;                             // pitch of tix (8 * lanes per column); merging waves
+  int n_merge;                                 // merging waves
   int select;                                  // one-workgroup-per-cell kernel: rank selection instead of the merge
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
@@ -606,119 +603,7 @@ __device__ __forceinline__ void merge_row(const ThrDev &pd, const float *colbuf_
 }
 
 
-// ---- the same merge, software-pipelined -----------------------------------------------------------------
-// merge_row issues a step in program order: three LDS reads, wait, 25 vector instructions, two writes -- the wave
-// sits out the LDS round trip and THEN issues everything.  But the next winner needs only two of those instructions:
-// the popped group's new top is max(new head, its old second) and the next winner is max(that, second cached top).
-// So a step here (1) takes the data its reads brought, (2) computes the next winner and ISSUES THE NEXT STEP'S READS,
-// and only then (3) finishes the group insertion, writes the group back and finishes the cached tops, all in the
-// shadow of the reads in flight.  The reads of step k+1 are therefore issued before the write-back of step k: when
-// both steps pop from the same group, the group's heads are taken from registers (three selects), not from the
-// stale strip; any older write is already ahead of the read in the wave's in-order LDS queue.  Same comparisons, same
-// results as merge_row.
-template <bool TOP, int NG>
-__device__ __forceinline__ void merge_row_pl(const ThrDev &pd, const float *colbuf_f, float *hbuf_f, uint32_t *posb,
-                                             const uint16_t *cl, int r, const RowFlags &rf, bool store, double *orow) {
-  static_assert(NG >= 1, "pipelined merge needs the grouped heads");
-  const int *colbuf = reinterpret_cast<const int *>(colbuf_f);
-  const int RP = pd.RP;
-  const int steps = TOP ? pd.steps_top : pd.steps_bot;
-  const int nt = TOP ? pd.nt_top : pd.nt_bot;
-  const int2 *tgt = TOP ? pd.tgt_top : pd.tgt_bot;
-  if (steps == 0) return;
-  const int worst = TOP ? kKeyMin : kKeyMax;
-  auto better = [](double a, double b) { return TOP ? pk_max(a, b) : pk_min(a, b); };
-  auto worse = [](double a, double b) { return TOP ? pk_min(a, b) : pk_max(a, b); };
-  double2 *sa = reinterpret_cast<double2 *>(hbuf_f);
-  double2 *sb = reinterpret_cast<double2 *>(posb);
-  double m[NG];
-  {
-    int clr[4 * NG];
-#pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) clr[j] = (j < pd.W) ? int(cl[j]) : 0;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      double hd[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 4 * g + i;
-        const int pos = (j < pd.W) ? clr[j] * pd.S_pad + (TOP ? 1 : pd.S) : 0;
-        hd[i] = pk_make((j < pd.W) ? colbuf[pos] : worst, (uint32_t(pos) << 2) | uint32_t(g));
-      }
-      sort_best_first<TOP, 4>(hd);
-      sa[g * RP + r] = make_double2(hd[0], hd[1]);
-      sb[g * RP + r] = make_double2(hd[2], hd[3]);
-      m[g] = hd[0];
-    }
-    sort_best_first<TOP, NG>(m);
-  }
-  int k = 0;
-  int next_rank = nt > 0 ? ldk(&tgt[0]).x : -1;
-  double prev = pk_make(worst, 0);
-
-  // reads of one step, in flight
-  int nk;            // next key of the popped column
-  double2 ha, hb;    // the popped group's strip: (top, 2nd), (3rd, 4th)
-  uint32_t lo_cur;   // low word of the popped head: position << 2 | group
-  int gidx_cur;
-  auto issue = [&](double top) {
-    lo_cur = uint32_t(__double2loint(top));
-    gidx_cur = __mul24(int(lo_cur & 3u), RP) + r;
-    nk = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(colbuf) + (lo_cur & 0x7ffffffcu) + (TOP ? 4 : -4));
-    ha = sa[gidx_cur];
-    hb = sb[gidx_cur];
-  };
-  // the previous step's group after its insertion (registers): what the strip will hold once its write-back lands
-  double b1 = 0.0, b2 = 0.0, b3 = 0.0;
-  int gidx_prev = -1;
-  issue(m[0]);
-  auto do_step = [&]() {
-    prev = m[0];
-    const uint32_t lo = lo_cur;
-    const int gidx = gidx_cur;
-    const bool same = gidx == gidx_prev;
-    const double h1 = same ? b1 : ha.y, h2 = same ? b2 : hb.x, h3 = same ? b3 : hb.y;
-    const double fresh = pk_make(nk, (lo & 0x7fffffffu) + (TOP ? 4u : -4u));
-    const double t0 = better(fresh, h1);  // the group's new top
-    double m0n = t0;
-    if constexpr (NG >= 2) m0n = better(t0, m[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    issue(m0n);  // next step's reads go out before anything else of this step is finished
-    __builtin_amdgcn_sched_barrier(0);
-    // finish the group: (fresh, h1, h2, h3) with h1 >= h2 >= h3 -> sorted best-first
-    const double w1 = worse(fresh, h1);
-    b1 = better(w1, h2);
-    const double w2 = worse(w1, h2);
-    b2 = better(w2, h3);
-    b3 = worse(w2, h3);
-    sa[gidx] = make_double2(t0, b1);
-    sb[gidx] = make_double2(b2, b3);
-    gidx_prev = gidx;
-    // finish the cached tops: (t0, m[1..NG)) -> sorted best-first
-    m[0] = m0n;
-    if constexpr (NG >= 2) {
-      double w = worse(t0, m[1]);
-#pragma unroll
-      for (int i = 1; i + 1 < NG; ++i) {
-        const double nb = better(w, m[i + 1]);
-        w = worse(w, m[i + 1]);
-        m[i] = nb;
-      }
-      m[NG - 1] = w;
-    }
-  };
-  int step = 0;
-  while (true) {
-    const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
-    for (; step < stop; ++step) do_step();
-    if (step >= steps) break;
-    // step == next_rank: m[0] is order statistic `step`, prev the one before it
-    emit_targets<TOP>(pd, tgt, nt, k, next_rank, step, pk_key(m[0]), pk_key(prev), rf, store, orow);
-    next_rank = __builtin_amdgcn_readfirstlane(next_rank);
-  }
-}
-
-template <int NG, bool PIPELINED = false>
+template <int NG>
 __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf, float *hbuf, uint32_t *posb,
                                            const uint32_t *flags, const uint16_t *cl, int r, bool store,
                                            double *orow) {
@@ -741,13 +626,8 @@ __device__ __forceinline__ void merge_both(const ThrDev &pd, const float *colbuf
     }
   }
   if (nan_or >> 31) rf.n_pos = -1;
-  if constexpr (PIPELINED && NG >= 1) {
-    merge_row_pl<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
-    merge_row_pl<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
-  } else {
-    merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
-    merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
-  }
+  merge_row<true, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
+  merge_row<false, NG>(pd, colbuf, hbuf, posb, cl, r, rf, store, orow);
 }
 
 
@@ -1308,283 +1188,6 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
   }
 }
 
-// ---- pipelined form (S <= 128): the workgroup's waves are specialised --------------------------
-// The merge is a latency-bound dependent chain that only ceil(rows/64) waves can work on, while
-// load + sort need no LDS at all when the sort runs in registers.  So waves [0, n_merge) merge block
-// k out of the LDS image while waves [n_merge, 8) gather block k+1 straight from HBM into the
-// register layout of the DPP-row sorter, sort it there and hold the keys until the image is free.
-// The workgroup is persistent (it walks cells blockIdx.x, blockIdx.x + gridDim.x, ...) so the
-// pipeline also runs across cell boundaries.  Two barriers per block: "image free / keys ready" and
-// "image written".  Results are identical to thresholds_kernel (same sort network, same merge).
-constexpr int kHold = 6;  // column groups a producer wave holds per block (8 VGPRs each)
-
-// NG (heads per row / 4; 0 = generic) is a kernel template parameter, not a run-time switch: a kernel that
-// carries every merge variant outgrows the instruction cache, and the misses showed up as 3-10x longer
-// start-up and write phases.
-template <int LPC, bool VEC, int NG>
-__global__ __launch_bounds__(kThrThreads, 4) void thresholds_pipe_kernel(ThrDev pd, const float *__restrict__ x,
-                                                                      int64_t n_cells,
-                                                                      double *__restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int nwaves = kThrThreads / 64;
-  constexpr int kCols = 64 / LPC;
-
-  size_t off = 0;
-  float *colbuf = reinterpret_cast<float *>(smem + off);
-  off += (size_t(pd.ncols_max) * pd.S_pad * 4 + 15) & ~size_t(15);
-  uint32_t *flags0 = reinterpret_cast<uint32_t *>(smem + off);  // census words, double-buffered by block parity
-  const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
-  off += 2 * size_t(flags_pitch) * 4;
-  float *hbuf = reinterpret_cast<float *>(smem + off);
-  off += size_t(pd.Wp) * pd.RP * 4;
-  uint32_t *posb = reinterpret_cast<uint32_t *>(smem + off);
-  off += size_t(pd.Wp) * pd.RP * 4;
-  uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][W] local columns of this block's windows
-
-  // One block of day-of-year rows per workgroup, for a strided set of cells: the block's tables are
-  // fixed for the workgroup's lifetime (window column lists staged in LDS once).
-  const int nb = pd.n_blocks;
-  const int blk = int(blockIdx.x) % nb;
-  const int64_t wg_per_blk = gridDim.x / nb;  // the host launches a multiple of n_blocks workgroups
-  const int64_t first_cell = int64_t(blockIdx.x) / nb;
-  const int64_t n_items = first_cell < n_cells ? (n_cells - first_cell + wg_per_blk - 1) / wg_per_blk : 0;
-  const int row0 = pd.blk_row0[blk];
-  const int nrows = pd.blk_nrows[blk];
-  const int ncols = pd.blk_ncols[blk];
-  const int32_t *tixb = pd.tix + size_t(pd.blk_col_off[blk]) * pd.SL;
-  for (int i = tid; i < nrows * pd.W; i += kThrThreads) cl_lds[i] = pd.cols_local[size_t(row0) * pd.W + i];
-
-  // Roles.  The merge is a dependent chain that issues about one instruction per 8 cycles, so two
-  // merging waves on one SIMD slow each other down (measured: +36 %) while a SIMD without any is
-  // wasted.  Waves therefore take roles by the SIMD they landed on (HW_ID.SIMD_ID): one merging wave
-  // per SIMD first, starting at SIMD 2*(thread-group slot & 1) so that the two workgroups resident on
-  // a CU use different SIMDs.  The assignment only steers performance; any outcome is correct.
-  const int n_merge = pd.n_merge;
-  const int n_prod = nwaves - n_merge;
-  __shared__ int s_simd[nwaves];
-  uint32_t hwid;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-  const int my_simd = HDP_DBG(pd, 64) ? (wave & 3) : int((hwid >> 4) & 3u);
-  const int tg_par = HDP_DBG(pd, 64) ? 0 : int((hwid >> 16) & 1u);
-  if (lane == 0) s_simd[wave] = my_simd;
-  __syncthreads();
-  int rank = 0;
-  {
-    // order: (how many lower-numbered waves share my SIMD, SIMD distance from the preferred one, wave)
-    int occ_me = 0;
-    for (int w = 0; w < wave; ++w) occ_me += (s_simd[w] == my_simd);
-    const int key_me = (occ_me * 4 + ((my_simd - 2 * tg_par) & 3)) * nwaves + wave;
-    for (int w = 0; w < nwaves; ++w) {
-      const int sw = s_simd[w];
-      int occ = 0;
-      for (int u = 0; u < w; ++u) occ += (s_simd[u] == sw);
-      const int key = (occ * 4 + ((sw - 2 * tg_par) & 3)) * nwaves + w;
-      rank += (key < key_me);
-    }
-  }
-  rank = __builtin_amdgcn_readfirstlane(rank);
-  const bool producer = rank >= n_merge;  // wave-uniform
-  // The merging wave needs an issue slot every few cycles and shares its SIMD with three producer
-  // waves whose sorts are VALU-dense: without priority its chain runs 35 % slower (measured).
-  if (producer) __builtin_amdgcn_s_setprio(0);
-  else __builtin_amdgcn_s_setprio(3);
-  const int pw = rank - n_merge;           // producer index
-  const int mrow = rank * 64 + lane;       // merging waves: row of the block this lane merges
-
-  // VEC (LPC == 16 and, for every sample e, the four columns of a group are adjacent in time; host-
-  // checked): lane `lane` loads 16 bytes = sample e = 64 k + lane of columns c..c+3, then a 4x4 transpose
-  // between registers and DPP rows (two v_permlane32_swap + two v_permlane16_swap) leaves row r with
-  // column c + r: 4x fewer memory requests than one dword per (column, sample).
-  int gc[VEC ? kHold : 1];  // first column of this producer wave's j-th group, -1: none (wave-uniform)
-  if constexpr (VEC) {
-    const int g0 = pd.blk_grp_off[blk], ng = pd.blk_grp_off[blk + 1] - g0;
-#pragma unroll
-    for (int j = 0; j < kHold; ++j) {
-      const int g = pw + j * n_prod;
-      gc[j] = __builtin_amdgcn_readfirstlane((producer && g < ng) ? pd.grp_col[g0 + g] : -1);
-    }
-  }
-
-  for (int64_t s = 0; s <= n_items; ++s) {
-    // sorted keys + census of this producer wave's column groups; defined and consumed inside one
-    // iteration, on the producer path only, so the merging waves' registers are not charged for them
-    float hold[kHold][8];
-    uint32_t *flags_p = flags0 + int(s & 1) * flags_pitch;        // census of block s (being produced)
-    const uint32_t *flags_m = flags0 + int((s + 1) & 1) * flags_pitch;  // census of block s - 1 (being merged)
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;  // debug & 32: phase clocks
-    const bool clocked = HDP_DBG(pd, 32) && lane == 0 && (rank == 0 || rank == n_merge);
-    if (clocked) c0 = c1 = __builtin_readcyclecounter();
-    const int64_t cell_p = first_cell + s * wg_per_blk;
-    if (producer) {
-      if (s < n_items) {
-        // ---- gather + sort block `s` in registers ------------------------------------------------
-        const float *xc = x + cell_p * int64_t(pd.T);
-        // tixb: time indices of this block's columns, [column][8 * LPC], -1 = no sample
-        // lane coordinates re-materialised here: anything derived from them stays inside the producer
-        // branch instead of being hoisted into registers that would be live across the merge
-        int grp = lane / LPC, l = lane % LPC;
-        asm volatile("" : "+v"(grp), "+v"(l));
-        // Loads are branch-free (groups past the end of the block re-read its last columns and are
-        // discarded).  All time indices first; then the samples of group j + 1 are requested just
-        // before group j is sorted, so a producer wave keeps one group of loads in flight, not six: a
-        // full vector-memory queue would also stall the merging waves' quantile stores (in-order issue).
-        int tt[VEC ? kHold : 1][2];
-        if constexpr (VEC) {
-#pragma unroll
-          for (int j = 0; j < kHold; ++j)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) tt[j][k] = tixb[size_t(max(gc[j], 0)) * pd.SL + k * 64 + lane];
-        } else {
-#pragma unroll
-          for (int j = 0; j < kHold; ++j) {
-            const int lc = min((pw + j * n_prod) * kCols + grp, ncols - 1);
-            const int4 *tp = reinterpret_cast<const int4 *>(tixb + size_t(lc) * pd.SL + l * 8);
-            const int4 ta = tp[0], tb = tp[1];
-            hold[j][0] = __int_as_float(ta.x); hold[j][1] = __int_as_float(ta.y);
-            hold[j][2] = __int_as_float(ta.z); hold[j][3] = __int_as_float(ta.w);
-            hold[j][4] = __int_as_float(tb.x); hold[j][5] = __int_as_float(tb.y);
-            hold[j][6] = __int_as_float(tb.z); hold[j][7] = __int_as_float(tb.w);
-          }
-        }
-        auto request = [&](int j) {  // samples of group j -> hold[j] (VEC: still register-major, see arrange)
-          if constexpr (VEC) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const int t = tt[j][k];
-              const float *src = (t >= 0 && !HDP_DBG(pd, 4)) ? xc + t : pd.ninf;  // pd.ninf: four -inf words
-              float4 v;
-              __builtin_memcpy(&v, src, 16);  // global_load_dwordx4, any 4-byte alignment
-              hold[j][4 * k + 0] = v.x; hold[j][4 * k + 1] = v.y; hold[j][4 * k + 2] = v.z; hold[j][4 * k + 3] = v.w;
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              // unconditional load through a selected base (slots without a sample read a -inf word):
-              // a select on the loaded value would make the compiler branch around every load and wait
-              const int t = __float_as_int(hold[j][i]);
-              const float *src = (t >= 0) ? xc : pd.ninf;
-              hold[j][i] = src[max(t, 0)];
-            }
-          }
-        };
-        auto finish = [&](int j) {  // (VEC: transpose,) census, sort
-          const int c0 = VEC ? gc[VEC ? j : 0] : (pw + j * n_prod) * kCols;
-          if (c0 >= 0 && c0 < ncols) {
-            if constexpr (VEC) {
-#pragma unroll
-              for (int k = 0; k < 2; ++k) {
-                const uint32_t a0 = __float_as_uint(hold[j][4 * k + 0]), a1 = __float_as_uint(hold[j][4 * k + 1]);
-                const uint32_t a2 = __float_as_uint(hold[j][4 * k + 2]), a3 = __float_as_uint(hold[j][4 * k + 3]);
-                auto s02 = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
-                auto s13 = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
-                auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
-                auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
-                hold[j][4 * k + 0] = __uint_as_float(s01[0]);  // sample 64 k + 16 i + (lane & 15) of column c + row
-                hold[j][4 * k + 1] = __uint_as_float(s01[1]);
-                hold[j][4 * k + 2] = __uint_as_float(s23[0]);
-                hold[j][4 * k + 3] = __uint_as_float(s23[1]);
-              }
-            }
-            const int cb = c0;
-            const bool active = (cb + grp) < ncols;
-            uint32_t cnt = 0;  // nan << 20 | +inf << 10 | -inf
-            bool special = false;
-            // sample index held in register i before the sort
-            auto slot = [&](int i) { return VEC ? (i >> 2) * 64 + (i & 3) * 16 + l : l * 8 + i; };
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const bool real = active && slot(i) < pd.S;
-              special |= real && ((__float_as_uint(hold[j][i]) & 0x7f800000u) == 0x7f800000u);
-            }
-            if (__ballot(special) != 0) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const bool real = active && slot(i) < pd.S;
-                float v = hold[j][i];
-                if (v != v) { cnt += 1u << 20; v = 0.0f; }
-                if (real && v == INFINITY) cnt += 1u << 10;
-                if (real && v == -INFINITY) cnt += 1u;
-                hold[j][i] = v;
-              }
-            }
-            if (!HDP_DBG(pd, 2)) sort_group_desc<LPC>(hold[j], l);
-            if constexpr (LPC >= 2) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor1, 0xf, 0xf, false);
-            if constexpr (LPC >= 4) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppXor2, 0xf, 0xf, false);
-            if constexpr (LPC >= 8) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppHalfMirror, 0xf, 0xf, false);
-            if constexpr (LPC >= 16) cnt += __builtin_amdgcn_update_dpp(0, (int)cnt, kDppMirror, 0xf, 0xf, false);
-            if (active && l == 0)
-              flags_p[cb + grp] = ((cnt >> 20) ? 0x80000000u : 0u) | (((cnt >> 10) & 0x3ffu) << 15) | (cnt & 0x3ffu);
-          }
-        };
-        request(0);
-        if (clocked) c1 = __builtin_readcyclecounter();
-#pragma unroll
-        for (int j = 0; j < kHold; ++j) {
-          if (j + 1 < kHold) request(j + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          finish(j);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    } else if (s >= 1) {
-      // ---- merge block `s - 1` out of the LDS image ----------------------------------------------
-      const int64_t cell = first_cell + (s - 1) * wg_per_blk;
-      if (mrow < nrows && !HDP_DBG(pd, 1)) {
-        const int row = row0 + mrow;
-        const uint16_t *cl = cl_lds + mrow * pd.W;
-        double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
-        merge_both<NG>(pd, colbuf, hbuf, posb, flags_m, cl, mrow, true, orow);
-      }
-    }
-    if (clocked) c2 = __builtin_readcyclecounter();
-    __syncthreads();  // image free (merge s-1 done), keys of block s sorted
-    if (clocked) c3 = __builtin_readcyclecounter();
-    if (producer && s < n_items) {
-      int grp = lane / LPC, l = lane % LPC;
-      asm volatile("" : "+v"(grp), "+v"(l));
-#pragma unroll
-      for (int j = 0; j < kHold; ++j) {
-        const int c0 = VEC ? gc[VEC ? j : 0] : (pw + j * n_prod) * kCols;
-        const int lc = c0 + grp;
-        if (c0 >= 0 && lc < ncols) {
-          float *col = colbuf + lc * pd.S_pad + 1;
-          // branch-free: slots past the column's last sample all land on its trailing sentinel
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int e = l * 8 + i;
-            const int key = (e < pd.S) ? f32_key(hold[j][i]) : kKeyMin;
-            col[min(e, pd.S)] = __int_as_float(key);
-          }
-          if (l == 0) {
-            col[-1] = __int_as_float(kKeyMax);     // below every ascending walk
-            col[pd.S] = __int_as_float(kKeyMin);   // below every descending walk
-          }
-        }
-      }
-    }
-    if (clocked) c4 = __builtin_readcyclecounter();
-    __syncthreads();  // image of block s ready
-    if (clocked) {
-      c5 = __builtin_readcyclecounter();
-      if (rank == 0) {  // merging wave: work, wait for the producers, wait for the image
-        atomicAdd(&pd.clk[0], c2 - c0);
-        atomicAdd(&pd.clk[1], c3 - c2);
-        atomicAdd(&pd.clk[2], c5 - c3);
-        atomicAdd(&pd.clk[3], 1ull);
-      } else if (!HDP_DBG(pd, 512)) {  // first producer wave: gather issue, sort (+ load wait), wait for the merge, write
-        atomicAdd(&pd.clk[4], c1 - c0);
-        atomicAdd(&pd.clk[5], c2 - c1);
-        atomicAdd(&pd.clk[6], c3 - c2);
-        atomicAdd(&pd.clk[7], c4 - c3);
-      }
-    }
-  }
-}
-
-
 // ---- lane-per-column producers (S <= 104): the column sort as a register network -----------------------
 // The 16-lane-row sorter above spends 10 of its 28 stages crossing lanes (a v_mov_dpp + v_med3 pair per key) and
 // pads every column to 128 slots.  Here ONE LANE owns one day-of-year column: its S samples sit in N >= S registers
@@ -1678,7 +1281,7 @@ __device__ __forceinline__ void landed(int &reg) { asm volatile("" : "+v"(reg));
 
 // slots below this index hold a sample for every S the N-slot kernel is chosen for (S > the next smaller N)
 constexpr int lane_first_pad_slot(int N) {
-  constexpr int kN[] = {0, 8, 16, 24, 32, 48, 64, 80, 100};
+  constexpr int kN[] = {0, 16, 32, 64, 80, 100};
   int prev = 0;
   for (int n : kN)
     if (n < N) prev = n;
@@ -2063,33 +1666,6 @@ static int launch_thr_epl(const ThrDev &pd, size_t lds, const float *x, int64_t 
                    : launch_thr_epl_sel<EPL, false>(pd, lds, x, n_cells, out, stream);
 }
 
-template <int LPC, bool VEC, int NG>
-static int launch_thr_pipe(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
-                           hipStream_t stream) {
-  auto kern = thresholds_pipe_kernel<LPC, VEC, NG>;
-  HDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // persistent workgroups: as many as the device keeps resident, each walking a strided set of cells
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    HDP_HIP_TRY(hipGetDevice(&dev));
-    HDP_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
-  int per_cu = 0;
-  HDP_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern),
-                                                           kThrThreads, lds));
-  if (per_cu < 1) per_cu = 1;
-  // a multiple of n_blocks: workgroup w works on block w % n_blocks for cells w / n_blocks + k * (grid / n_blocks)
-  const int64_t nb = pd.n_blocks;
-  int64_t resident = int64_t(per_cu) * n_cu;
-  if (pd.grid_override > 0) resident = pd.grid_override;
-  int64_t grid = std::max<int64_t>(1, std::min<int64_t>(resident / nb, n_cells)) * nb;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThrThreads), lds, stream, pd, x, n_cells, out);
-  HDP_HIP_TRY(hipGetLastError());
-  return HDP_OK;
-}
-
 // persistent grid shared by the pipelined and the lane-per-column kernel: as many workgroups as the device keeps
 // resident, a multiple of n_blocks (workgroup w works on block w % n_blocks for cells w / n_blocks + k * (grid / n_blocks))
 // hdp_threshold_plan_reserve: walk the launch path, allocate what a launch of that size would, launch nothing
@@ -2140,16 +1716,7 @@ static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t
   const bool whole = pd.n_blocks == 1 && pd.RP > kLeanRows;  // the plan put every row of a cell into one workgroup
   const int threads = std::min<int>(whole ? kWholeThreads : kThrThreads, 64 * (pd.n_merge + (n_tasks + tpw - 1) / tpw));
   switch (pd.Wp >> 2) {
-    case 1:
-      if constexpr (N > 64) {
-        if (pd.tier_k < pd.S && whole)
-          return launch_thr_persistent(thresholds_lane_kernel<N, 1, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
-        if (pd.tier_k < pd.S)
-          return launch_thr_persistent(thresholds_lane_kernel<N, 1, true, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
-      }
-      if (whole)
-        return launch_thr_persistent(thresholds_lane_kernel<N, 1, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
-      return launch_thr_persistent(thresholds_lane_kernel<N, 1, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
+    case 1:  // windows of up to four columns run the two-group kernels (their lists are padded with the pseudo column)
     case 2:
       if constexpr (N > 64) {
         if (pd.tier_k < pd.S && whole)
@@ -2176,39 +1743,27 @@ static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t
 
 // register slots per column the lane-per-column kernel is instantiated for (0: S too large)
 static int lane_slots_for(int64_t S) {
-  static const int kN[] = {8, 16, 24, 32, 48, 64, 80, 100};
+  static const int kN[] = {16, 32, 64, 80, 100};  // register slots per column the kernel is instantiated for (80: so that
+                                                      // the 100-slot kernel's first 80 slots always hold a sample -- constant addresses)
   for (int n : kN)
     if (S <= n) return n;
   return 0;
 }
 static int lane_tasks_per_wave_rt(int N) { return N >= 64 ? 1 : (N >= 32 ? 2 : 4); }
 
-// run-time (lanes per column, 16-byte gathers, head groups) -> kernel instantiation
-template <int LPC, bool VEC>
-static int launch_thr_pipe_ng(const ThrDev &pd, size_t lds, const float *x, int64_t n_cells, double *out,
-                              hipStream_t stream) {
-  switch (pd.Wp >> 2) {
-    case 1: return launch_thr_pipe<LPC, VEC, 1>(pd, lds, x, n_cells, out, stream);
-    case 2: return launch_thr_pipe<LPC, VEC, 2>(pd, lds, x, n_cells, out, stream);
-    case 4: return launch_thr_pipe<LPC, VEC, 4>(pd, lds, x, n_cells, out, stream);
-    default: return launch_thr_pipe<LPC, VEC, 0>(pd, lds, x, n_cells, out, stream);
-  }
-}
-
 // Which kernel a launch of this plan runs: the plan's choice under the HDP_THR_* selectors that were in the
 // environment WHEN THE PLAN WAS CREATED (tests create one plan per variant to compare them on the same input).
 struct ThrVariant {
-  bool lane, pipe, vec, select;
+  bool lane, select;
 };
 static ThrVariant thr_variant(const hdp_threshold_plan *plan, int debug) {
   ThrVariant v;
-  const bool pipe_allowed = plan->opt_pipe != 0 && !(debug & 8);
-  v.lane = plan->lane && pipe_allowed && plan->opt_lane != 0;
-  v.pipe = !v.lane && plan->pipe && pipe_allowed;
-  v.vec = v.pipe && plan->lpc == 16 && plan->vec && plan->opt_vec != 0;
+  // HDP_THR_LANE=0 (or the older HDP_THR_PIPE=0) selects the one-workgroup-per-cell kernel for A/B
+  const bool lane_allowed = plan->opt_pipe != 0 && !(debug & 8);
+  v.lane = plan->lane && lane_allowed && plan->opt_lane != 0;
   // rank selection pays once the merge is deep (a lane per (row, rank) instead of a lane per row);
   // HDP_THR_SELECT=0/1 forces the choice for tests
-  const bool wg_per_cell = !v.lane && !v.pipe;
+  const bool wg_per_cell = !v.lane;
   v.select = wg_per_cell && (plan->W <= 16) && (plan->steps_top + plan->steps_bot >= 512);
   if (plan->opt_select >= 0) v.select = wg_per_cell && (plan->W <= 16) && plan->opt_select != 0;
   if (plan->select_only) v.select = true;  // the plan's LDS image has no room for merge heads
@@ -2223,16 +1778,10 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
     snprintf(buf, sizeof buf,
              "thresholds_lane_kernel<N=%d,NG=%d%s> (one lane per column: register merge-exchange sort; %d merging waves; "
              "%d rows x %d blocks, %zu B LDS%s)",
-             plan->lane_n, plan->Wp >> 2,
+             plan->lane_n, std::max(2, plan->Wp >> 2),
              plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : (plan->n_blocks == 1 && plan->RP > hdp::kLeanRows ? ",whole-cell" : (plan->lane_dual ? ",dual" : "")), plan->lane_n_merge,
              plan->rows_per_block, plan->n_blocks, plan->lane_lds_bytes,
              plan->lane_tier_k < plan->S ? "; top 60 samples of a column in LDS, the rest in a global tail" : "");
-  else if (v.pipe)
-    snprintf(buf, sizeof buf,
-             "thresholds_pipe_kernel<LPC=%d,%s,NG=%d> (register sort producers + %d merging waves; %d rows x %d blocks, "
-             "%zu B LDS)",
-             plan->lpc, v.vec ? "16-byte gathers" : "dword gathers", (plan->Wp >> 2) <= 4 ? (plan->Wp >> 2) : 0,
-             plan->n_merge, plan->rows_per_block, plan->n_blocks, plan->lds_bytes);
   else
     snprintf(buf, sizeof buf,
              "thresholds_kernel<EPL=%d,%s> (one workgroup per cell: LDS columns, wave sort, %s; <= %d rows x %d blocks%s, "
@@ -2276,12 +1825,6 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.nt_top = plan->nt_top;
   pd.nt_bot = plan->nt_bot;
   pd.n = (int)plan->n;
-  pd.tix = plan->tix.as<int32_t>();
-  pd.blk_col_off = plan->blk_col_off.as<int32_t>();
-  pd.ninf = plan->ninf.as<float>();
-  pd.blk_grp_off = plan->blk_grp_off.as<int32_t>();
-  pd.grp_col = plan->grp_col.as<int32_t>();
-  pd.SL = 8 * plan->lpc;
   pd.n_merge = plan->n_merge;
   pd.dual = 0;
   pd.tixl = plan->tixl.as<int32_t>();
@@ -2313,29 +1856,12 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
     pd.n_merge = plan->lane_n_merge;
     pd.dual = plan->lane_dual ? 1 : 0;
     switch (plan->lane_n) {
-      case 8: return launch_thr_lane<8>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
       case 16: return launch_thr_lane<16>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
-      case 24: return launch_thr_lane<24>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
       case 32: return launch_thr_lane<32>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
-      case 48: return launch_thr_lane<48>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
       case 64: return launch_thr_lane<64>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
       case 80: return launch_thr_lane<80>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
       case 100: return launch_thr_lane<100>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
       default: return set_error(HDP_EUNSUP, "lane-per-column kernel: no instantiation for %d slots", plan->lane_n);
-    }
-  }
-  if (var.pipe) {
-    switch (plan->lpc) {
-      case 1: return launch_thr_pipe_ng<1, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      case 2: return launch_thr_pipe_ng<2, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      case 4: return launch_thr_pipe_ng<4, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      case 8: return launch_thr_pipe_ng<8, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      default: {
-        if (HDP_DBG(pd, 4096)) fprintf(stderr, "[hdp thresholds] %s\n", hdp_threshold_plan_describe(plan));
-        if (var.vec)
-          return launch_thr_pipe_ng<16, true>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-        return launch_thr_pipe_ng<16, false>(pd, plan->lds_bytes, x_dev, n_cells, out_dev, stream);
-      }
     }
   }
   switch (plan->epl) {
@@ -2452,7 +1978,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   auto *pl = new hdp_threshold_plan();
   pl->n_doy = n_doy; pl->S = S; pl->W = W; pl->P = P; pl->T = T;
   pl->opt_pipe = (int32_t)hdp::env_option("HDP_THR_PIPE", -1);
-  pl->opt_vec = (int32_t)hdp::env_option("HDP_THR_VEC", -1);
   pl->opt_select = (int32_t)hdp::env_option("HDP_THR_SELECT", -1);
   pl->opt_lane = (int32_t)hdp::env_option("HDP_THR_LANE", -1);
   pl->opt_grid = hdp::env_option("HDP_THR_GRID", 0);
@@ -2553,22 +2078,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
         const int c = cols[int64_t(r) * W + j];
         if (!seen[c]) { seen[c] = 1; set.push_back(c); }
       }
-    if (S > 64 && S <= 128 && n_doy >= 4) {
-      // 16-byte gathers work on runs of >= 4 consecutive day-of-year columns: a shorter run (the lone
-      // column 0 that the reflected upper edge keeps, threshold.py:43-48) is padded with its
-      // neighbours -- loaded and sorted like the rest, referenced by no window
-      for (int d = 0; d < n_doy;) {
-        if (!seen[d]) { ++d; continue; }
-        int e = d;
-        while (e + 1 < n_doy && seen[e + 1]) ++e;  // run [d, e]
-        for (int need = 4 - (e - d + 1); need > 0; --need) {
-          if (e + 1 < n_doy) { ++e; if (!seen[e]) { seen[e] = 2; set.push_back(e); } }
-          else if (d > 0) { --d; if (!seen[d]) { seen[d] = 2; set.push_back(d); } }
-        }
-        while (e + 1 < n_doy && seen[e + 1]) ++e;  // the padding may have touched the next run
-        d = e + 1;
-      }
-    }
     std::sort(set.begin(), set.end());
   };
   auto max_lds_for_rows = [&](int rows, int *ncols_max) -> size_t {
@@ -2592,12 +2101,12 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   bool whole = false;
   size_t whole_lds = 0;
   {
-    const int ngw0 = pl->Wp >> 2;
+    const int ngw0 = std::max(2, pl->Wp >> 2);  // the lane kernel's head groups: instantiated for 2 and 4 (windows of <= 4 columns run as 2)
     // tiered (more than 64 samples per column: top-side quantiles only, bottom walks would start in the global tail) or
     // with whole columns in LDS (up to 64 samples: any quantiles)
     const bool tiered = S > 64;
     // (a walk deeper than ~8 samples per column and tier slot would spend its steps fetching from the global tail)
-    const bool cand = S >= 3 && S <= 100 && (!tiered || (pl->steps_bot == 0 && pl->steps_top <= 8 * hdp::kTierK)) && (ngw0 == 1 || ngw0 == 2 || ngw0 == 4) &&
+    const bool cand = S >= 3 && S <= 100 && (!tiered || (pl->steps_bot == 0 && pl->steps_top <= 8 * hdp::kTierK)) && (ngw0 == 2 || ngw0 == 4) &&
                       pl->opt_lane != 0 && pl->opt_pipe != 0 && opt_rows <= 0 && hdp::env_option("HDP_THR_WHOLE", 1) != 0;
     if (cand && n_doy <= hdp::kWholeRows && n_doy > hdp::kLeanRows) {
       int ip = tiered ? hdp::kTierK + 3 : spad;
@@ -2645,24 +2154,10 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     return set_error(HDP_EUNSUP, "window of %lld x %lld samples does not fit the 160 KiB LDS",
                      (long long)W, (long long)S);
   }
-  // pipelined kernel (register sort, S <= 128): at most 6 merging waves, and every producer wave must
-  // be able to hold its share of the block's column groups; shrink the block if that is all it takes
-  int lpc = 0;
-  if (S <= 128) {
-    lpc = 1;
-    while (8 * lpc < S) lpc <<= 1;
-  }
-  auto pipe_ok = [&](int r, int ncols_max) -> bool {
-    if (!lpc) return false;
-    const int nm = (r + 63) / 64, np = hdp::kThrThreads / 64 - nm;
-    if (np < 2) return false;
-    const int kc = 64 / lpc, ng = (ncols_max + kc - 1) / kc;
-    return (ng + np - 1) / np <= hdp::kHold;
-  };
   // lane-per-column kernel: every producer wave sorts (and holds) up to lane_tasks_per_wave tasks of 64 columns
-  const int ngw = pl->Wp >> 2;  // head groups of four: the merge is instantiated for 1, 2 and 4
+  const int ngw = std::max(2, pl->Wp >> 2);  // head groups of four of the lane kernel: instantiated for 2 and 4
   // (S >= 3: the pseudo column that pads the window lists must lose from slot 1 going down AND from slot S going up)
-  const int lane_n = ((ngw == 1 || ngw == 2 || ngw == 4) && S >= 3) ? hdp::lane_slots_for(S) : 0;
+  const int lane_n = ((ngw == 2 || ngw == 4) && S >= 3) ? hdp::lane_slots_for(S) : 0;
   auto lane_ok = [&](int r, int ncols_max) -> bool {
     if (!lane_n) return false;
     const int nm = (r + 63) / 64, np = hdp::kThrThreads / 64 - nm;
@@ -2670,7 +2165,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     return (ncols_max + 63) / 64 <= np * hdp::lane_tasks_per_wave_rt(lane_n);
   };
   bool lane = whole || lane_ok(rows, cm);
-  bool pipe = !whole && pipe_ok(rows, cm);
   if (lane_n && !lane && !rows_forced) {
     for (int r = rows - 1; r >= std::max(1, rows / 2); --r) {
       const int nb = int((n_doy + r - 1) / r);
@@ -2678,7 +2172,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
       int c2 = 0;
       if (max_lds_for_rows(rb, &c2) <= kMaxLds && lane_ok(rb, c2)) {
         rows = rb; cm = c2; lane = true;
-        pipe = pipe_ok(rows, cm);
         break;
       }
     }
@@ -2727,26 +2220,12 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
         if (bd > (kMaxLds + 1024) / 2 - 512) continue;  // two workgroups per CU
         rows = rb;
         cm = c2;
-        pipe = pipe_ok(rows, cm);
         pl->lane_dual = true;
         pl->lane_lds_bytes = bd;
         break;
       }
     }
   }
-  if (lpc && !pipe && !lane && !rows_forced) {
-    for (int r = rows - 1; r >= std::max(1, rows / 2); --r) {
-      const int nb = int((n_doy + r - 1) / r);
-      const int rb = int((n_doy + nb - 1) / nb);
-      int c2 = 0;
-      if (max_lds_for_rows(rb, &c2) <= kMaxLds && pipe_ok(rb, c2)) {
-        rows = rb; cm = c2; pipe = true;
-        break;
-      }
-    }
-  }
-  pl->pipe = pipe;
-  pl->lpc = lpc;
   pl->n_merge = (rows + 63) / 64;
   pl->lane_n_merge = pl->lane_dual ? 2 * pl->n_merge : pl->n_merge;
   pl->rows_per_block = rows;
@@ -2893,59 +2372,6 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   up(pl->qparam, qp.data(), qp.size() * sizeof(hdp::QuantileParam));
   up(pl->tgt_top, ttop.data(), ttop.size() * sizeof(int2));
   up(pl->tgt_bot, tbot.data(), tbot.size() * sizeof(int2));
-  if (lpc) {
-    const int SL = 8 * lpc;
-    std::vector<int32_t> tix(cdoy.size() * SL, -1);  // one row per (block, local column)
-    for (size_t c = 0; c < cdoy.size(); ++c)
-      for (int64_t e = 0; e < S; ++e) {
-        int64_t t = time_index[int64_t(cdoy[c]) * S + e];
-        if (t < 0) t += T;
-        tix[c * SL + e] = (int32_t)t;
-      }
-    up(pl->tix, tix.data(), tix.size() * 4);
-    up(pl->blk_col_off, coff.data(), coff.size() * 4);
-    const float ninf4[4] = {-std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(),
-                            -std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity()};
-    up(pl->ninf, ninf4, sizeof ninf4);
-    // 16-byte gathers (lpc == 16): the block's columns are cut into runs of columns that are adjacent
-    // time steps for every sample; each run becomes groups of four (the last one of a run overlaps its
-    // neighbour).  A run shorter than four, or more groups than the producers can hold, disables it.
-    bool vec = (lpc == 16);
-    std::vector<int32_t> goff, gcol;  // per block: offset into gcol; first column of each group
-    const int n_prod = hdp::kThrThreads / 64 - pl->n_merge;
-    for (int b = 0; vec && b < pl->n_blocks; ++b) {
-      goff.push_back((int32_t)gcol.size());
-      const int nc = ncols[b];
-      int run0 = 0;
-      for (int c = 1; vec && c <= nc; ++c) {
-        bool adjacent = c < nc;
-        if (adjacent) {
-          const int32_t *ra = &tix[size_t(coff[b] + c - 1) * SL], *rb = &tix[size_t(coff[b] + c) * SL];
-          for (int64_t e = 0; e < S; ++e)
-            if (rb[e] != ra[e] + 1) { adjacent = false; break; }
-        }
-        if (!adjacent) {  // run [run0, c)
-          const int len = c - run0;
-          if (len < 4) {
-            vec = false;
-            break;
-          }
-          for (int o = 0; o < len; o += 4) gcol.push_back(run0 + std::min(o, len - 4));
-          run0 = c;
-        }
-      }
-      const int ng = int(gcol.size()) - goff.back();
-      if (vec && (ng + n_prod - 1) / n_prod > hdp::kHold) {
-        vec = false;
-      }
-    }
-    if (vec) {
-      goff.push_back((int32_t)gcol.size());
-      up(pl->blk_grp_off, goff.data(), goff.size() * 4);
-      up(pl->grp_col, gcol.data(), gcol.size() * 4);
-    }
-    pl->vec = vec;
-  }
   if (pl->lane) {
     // per block [N][64 * tasks]: BYTE offset of sample s of local column c (pad lanes repeat the last column)
     std::vector<int32_t> tl, tloff;
@@ -2999,13 +2425,7 @@ extern "C" int hdp_threshold_plan_destroy(hdp_threshold_plan *plan) {
       fprintf(stderr, "  | mean SIMD of merging ranks:");
       for (int r = 0; r < 6; ++r) fprintf(stderr, " %.2f", double(c[20 + r]) / c[3]);
       fprintf(stderr, "\n");
-    } else if (c[3] && (c[4] | c[5]))
-      fprintf(stderr,
-              "[hdp thresholds pipe] items=%llu  ticks/item: merge=%.0f wait_producers=%.0f wait_image=%.0f | "
-              "producer: gather=%.0f sort=%.0f wait_merge=%.0f write=%.0f\n",
-              c[3], double(c[0]) / c[3], double(c[1]) / c[3], double(c[2]) / c[3], double(c[4]) / c[3],
-              double(c[5]) / c[3], double(c[6]) / c[3], double(c[7]) / c[3]);
-    else if (c[3])
+    } else if (c[3])
       fprintf(stderr, "[hdp thresholds] blocks=%llu  ticks/block: load=%.0f sort=%.0f merge=%.0f\n", c[3],
               double(c[0]) / c[3], double(c[1]) / c[3], double(c[2]) / c[3]);
   }

@@ -449,8 +449,8 @@ def test_c2_full_size_cross_kernel_properties(monkeypatch):
 def test_c3_shape_slice_cross_kernel_properties(monkeypatch):
     """BASELINE config 3's series shape (36500 d = 100 noleap years, S = 100 samples per day of year, 151-step
     merges, 100 seasons) on a 2048-cell slice spanning both hemispheres -- the kernel variants the headline
-    bench runs (16-byte-gather pipelined thresholds kernel, packed series-per-lane state machine):
-      * pipelined / one-workgroup-per-cell merge / rank-selection thresholds kernels agree bit for bit;
+    bench runs (lane-per-column thresholds kernel, packed series-per-lane state machine):
+      * lane-per-column / one-workgroup-per-cell merge / rank-selection thresholds kernels agree bit for bit;
       * packed 16-bit, 32-bit and (percentile, definition)-per-lane metrics kernels agree bit for bit;
       * monotone thresholds, HWF >= HWD >= HWA >= 0, HWN <= HWF, HWA == HWF // HWN;
       * a sample of cells matches the C oracle exactly."""
@@ -471,7 +471,7 @@ def test_c3_shape_slice_cross_kernel_properties(monkeypatch):
     assert ti.shape == (365, 100)
     thr = core.compute_percentiles(base, ti, cols, q)
     assert thr.shape == (n, 365, 10) and not np.isnan(thr).any() and np.all(np.diff(thr, axis=2) >= 0)
-    monkeypatch.setenv("HDP_THR_LANE", "0")        # the pipelined kernel instead of the lane-per-column one
+    monkeypatch.setenv("HDP_THR_LANE", "0")        # the one-workgroup-per-cell kernel instead of the lane-per-column one
     assert same_f64(thr, core.compute_percentiles(base, ti, cols, q))
     monkeypatch.delenv("HDP_THR_LANE")
     monkeypatch.setenv("HDP_THR_PIPE", "0")

@@ -1,13 +1,10 @@
 """Every thresholds kernel variant against the C oracle and against each other (bit-exact).
 
 The library picks a kernel from the plan: the lane-per-column kernel (up to 100 samples per column and 16 window
-columns: one lane sorts one column in registers by a merge-exchange network; HDP_THR_LANE=0 turns it off), the
-pipelined kernel (wave-specialised, register sort with
-8 * LPC keys per column, LPC in {1, 2, 4, 8, 16}; 16-byte gathers when the calendar is regular; merge
-templated on the number of head groups NG in {1, 2, 4}, generic rescan for wider windows) or the
-one-workgroup-per-cell kernel (HDP_THR_PIPE=0, also the path for more than 128 samples per column), which
-finishes a block either with the merge or, when the requested ranks lie deep (HDP_THR_SELECT), with a rank
-selection per (row, requested rank).
+columns: one lane sorts one column in registers by a merge-exchange network; whole-cell or blocked form; HDP_THR_LANE=0
+turns it off) or the one-workgroup-per-cell kernel (every other plan: more than 100 samples per column, wider
+windows), which finishes a block either with the merge or, when the requested ranks lie deep (HDP_THR_SELECT), with a
+rank selection per (row, requested rank).  (The round-1 pipelined kernel that used to sit between the two is gone.)
 The environment switches are read when a plan is created (core.compute_percentiles makes one per call), so one
 process can run them all on the same input.
 """
@@ -83,8 +80,7 @@ def test_all_thresholds_kernels_agree_with_the_oracle(case, monkeypatch):
     # blocked form with the two walks of a row on different merging waves (plans with a top AND a bottom walk), and without
     assert same_f64(run(HDP_THR_WHOLE="0", HDP_THR_DUAL="1"), want)
     assert same_f64(run(HDP_THR_WHOLE="0", HDP_THR_DUAL="0"), want)
-    assert same_f64(run(HDP_THR_LANE="0"), want)      # pipelined kernel (16-byte gathers on regular calendars)
-    assert same_f64(run(HDP_THR_LANE="0", HDP_THR_VEC="0"), want)   # pipelined kernel, one dword per (column, sample)
+    assert same_f64(run(HDP_THR_LANE="0"), want)      # one workgroup per cell, merge or selection as the plan chooses
     assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="0"), want)   # one workgroup per cell, merge
     assert same_f64(run(HDP_THR_PIPE="0", HDP_THR_SELECT="1"), want)   # same, rank selection per (row, rank)
 
@@ -110,7 +106,7 @@ def test_tiered_image_deep_columns_reach_the_global_tail():
     assert same_f64(core.compute_percentiles(x, ti, cols, q), want)
 
 
-def test_pipelined_kernel_many_cells_vs_single_cell_launches():
+def test_persistent_kernel_many_cells_vs_single_cell_launches():
     """Persistent workgroups walk cells with a stride; every cell must come out as if it were alone
     (no state leaks between the items of a workgroup, odd cell counts, more workgroups than cells)."""
     rng = np.random.default_rng(77)
@@ -159,7 +155,7 @@ def test_random_calendars_windows_and_quantiles(seed, monkeypatch):
     win = cal.expand_window_table(ti, cols)
     with np.errstate(invalid="ignore"):
         want = c_oracle.thresholds(x, win, q)
-    for env in ({}, {"HDP_THR_WHOLE": "0"}, {"HDP_THR_LANE": "0"}, {"HDP_THR_LANE": "0", "HDP_THR_VEC": "0"},
+    for env in ({}, {"HDP_THR_WHOLE": "0"}, {"HDP_THR_LANE": "0"},
                 {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "0"}, {"HDP_THR_PIPE": "0", "HDP_THR_SELECT": "1"},
                 {"HDP_THR_WHOLE": "0", "HDP_THR_DUAL": "1"}, {"HDP_THR_WHOLE": "0", "HDP_THR_DUAL": "0"}):
         for k in ("HDP_THR_PIPE", "HDP_THR_VEC", "HDP_THR_SELECT", "HDP_THR_LANE", "HDP_THR_WHOLE", "HDP_THR_DUAL"):
