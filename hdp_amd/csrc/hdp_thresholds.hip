@@ -1498,7 +1498,12 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
               }
               col[kTierK] = __uint_as_float(0x7ff00000u | uint32_t(lc));
               col[kTierK + 1] = __uint_as_float(kRawMin);  // what the heads of window slots past W read
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail stores are asm: the barrier's own wait does not count them
+              // the tail stores are asm (the compiler does not count them) and a merging wave may read them back from L2:
+              // they must have landed before the barrier that opens the item's merge.  (Round 4 measured two alternatives,
+              // both without gain: waiting after that barrier while the rare tail branch polls a counter -- the poll loop
+              // re-shaped the merge step's code, +8 % -- and barriers that fence LDS only, so that nobody drains its
+              // global stores at them -- 12.4 ms per 131 072 cells either way.)
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             col[-1] = __uint_as_float(kRawMax);    // loses every ascending walk
           }
@@ -1718,24 +1723,30 @@ static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t
   switch (pd.Wp >> 2) {
     case 1:  // windows of up to four columns run the two-group kernels (their lists are padded with the pseudo column)
     case 2:
+      // whole-cell form: tiered image for columns of more than 64 samples (the plan makes every such whole-cell plan
+      // tiered), whole columns in LDS up to 64
       if constexpr (N > 64) {
-        if (pd.tier_k < pd.S && whole)
+        if (whole) {
+          HDP_REQUIRE(pd.tier_k < pd.S, HDP_EUNSUP, "whole-cell plan without a tiered image for S = %d", pd.S);
           return launch_thr_persistent(thresholds_lane_kernel<N, 2, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
-        if (pd.tier_k < pd.S)
-          return launch_thr_persistent(thresholds_lane_kernel<N, 2, true, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+        }
+      } else {
+        if (whole)
+          return launch_thr_persistent(thresholds_lane_kernel<N, 2, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
       }
-      if (whole)
-        return launch_thr_persistent(thresholds_lane_kernel<N, 2, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
       return launch_thr_persistent(thresholds_lane_kernel<N, 2, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
     case 4:
+      // whole-cell form: tiered image for columns of more than 64 samples (the plan makes every such whole-cell plan
+      // tiered), whole columns in LDS up to 64
       if constexpr (N > 64) {
-        if (pd.tier_k < pd.S && whole)
+        if (whole) {
+          HDP_REQUIRE(pd.tier_k < pd.S, HDP_EUNSUP, "whole-cell plan without a tiered image for S = %d", pd.S);
           return launch_thr_persistent(thresholds_lane_kernel<N, 4, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
-        if (pd.tier_k < pd.S)
-          return launch_thr_persistent(thresholds_lane_kernel<N, 4, true, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+        }
+      } else {
+        if (whole)
+          return launch_thr_persistent(thresholds_lane_kernel<N, 4, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
       }
-      if (whole)
-        return launch_thr_persistent(thresholds_lane_kernel<N, 4, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
       return launch_thr_persistent(thresholds_lane_kernel<N, 4, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
     default: return set_error(HDP_EUNSUP, "lane-per-column kernel: unsupported window width");
   }
@@ -2425,7 +2436,13 @@ extern "C" int hdp_threshold_plan_destroy(hdp_threshold_plan *plan) {
       fprintf(stderr, "  | mean SIMD of merging ranks:");
       for (int r = 0; r < 6; ++r) fprintf(stderr, " %.2f", double(c[20 + r]) / c[3]);
       fprintf(stderr, "\n");
-    } else if (c[3])
+    } else if (c[3] && (c[4] | c[5]))  // HDP_THR_DEBUG=32: the lane kernel's first merging wave and first producer
+      fprintf(stderr,
+              "[hdp thresholds lane] items=%llu  ticks/item: merge=%.0f wait_producers=%.0f wait_image=%.0f | "
+              "producer: loads=%.0f census+sort=%.0f wait_merge=%.0f image_write=%.0f\n",
+              c[3], double(c[0]) / c[3], double(c[1]) / c[3], double(c[2]) / c[3], double(c[4]) / c[3],
+              double(c[5]) / c[3], double(c[6]) / c[3], double(c[7]) / c[3]);
+    else if (c[3])
       fprintf(stderr, "[hdp thresholds] blocks=%llu  ticks/block: load=%.0f sort=%.0f merge=%.0f\n", c[3],
               double(c[0]) / c[3], double(c[1]) / c[3], double(c[2]) / c[3]);
   }
