@@ -120,8 +120,9 @@ struct hdp_threshold_plan {
     if (tm_stream) (void)hipStreamDestroy(tm_stream);
   }
   // lane-per-column kernel (S <= 100, W <= 16): one lane sorts one column in registers, no cross-lane stage
-  bool lane_dual = false;        // blocked lane kernel: top and bottom walks of a row on different merging waves
-  int32_t lane_n_merge = 0;      // merging waves of the lane kernel (twice n_merge in the dual form)
+  int32_t lane_n_segs = 0;       // blocked lane kernel, segmented walks: runs of requested ranks, each on its own merging waves
+  hdp::DevBuf lane_segs;         // ThrSeg [lane_n_segs]
+  int32_t lane_n_merge = 0;      // merging waves of the lane kernel (runs x n_merge in the segmented form)
   bool lane = false;
   int32_t lane_n = 0;            // register slots per column: the kernel's template parameter N >= S
   size_t lane_lds_bytes = 0;     // dynamic LDS of the lane kernel (its head strips are smaller)

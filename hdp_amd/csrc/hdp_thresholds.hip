@@ -36,6 +36,17 @@
 
 namespace hdp {
 
+struct ThrSeg {  // one run of requested ranks of a row (device-visible POD, 32 bytes)
+  int32_t top;        // 1: descending merge (ranks counted from the largest sample), 0: ascending
+  int32_t pivot_pos;  // > 0: enter the merge at the value of the window's centre column at this position (1-based, from
+                      //      the walk's own end); 0: enter at the end of the window
+  int32_t limit;      // entry is valid while no more than this many samples rank before the pivot (first rank - 1)
+  int32_t tgt_off;    // first target of the run in tgt_top / tgt_bot
+  int32_t nt;         // targets of the run
+  int32_t steps;      // last target's rank + 1
+  int32_t pad0, pad1;
+};
+
 struct ThrDev {
   const int32_t *blk_row0, *blk_nrows, *blk_ncols, *blk_list_off, *blk_list_len;
   const int2 *load_list;
@@ -47,7 +58,10 @@ struct ThrDev {
   // lane-per-column kernel, tiered image: the top `tier_k` samples of a column live in LDS (column pitch `img_pitch`
   // words), samples tier_k.. in a per-workgroup global tail [parity][sample - tier_k][tail_pitch] (tier_k == S: all in LDS)
   int tier_k, img_pitch, tail_pitch;
-  int dual;  // lane kernel, blocked form: the descending and the ascending walk of a row on two different merging waves
+  // lane kernel, blocked form, SEGMENTED walks (round 4): the requested ranks of a row are cut into up to kMaxSegs runs; a
+  // run is walked by its own merging wave (own head strips), entered at a PIVOT instead of at the end of the window
+  int n_segs;            // 0: classic (one lane walks a row's descending and then its ascending merge)
+  const struct ThrSeg *segs;
   float *tail;
   int n_merge;                                 // merging waves
   int select;                                  // one-workgroup-per-cell kernel: rank selection instead of the merge
@@ -683,12 +697,27 @@ __device__ __forceinline__ TgtLanes load_tgt_lanes(const ThrDev &pd, int lane) {
   }
   return t;
 }
+// the same for one run of a segmented plan: targets tgt[0 .. nt)
+__device__ __forceinline__ TgtLanes load_tgt_lanes_seg(const ThrDev &pd, const int2 *tgt, int nt, int lane) {
+  TgtLanes t{-1, 0, 0, 0.0, 0.0, nt <= 64};
+  if (t.ok && lane < nt) {
+    const int2 r = tgt[lane];
+    const QuantileParam qp = pd.qp[r.y & 0xffff];
+    t.rank = r.x;
+    t.slot = r.y;
+    t.mode = qp.mode;
+    t.w_lo = qp.w_lo;
+    t.w_hi = qp.w_hi;
+  }
+  return t;
+}
 __device__ __forceinline__ double readlane_f64(double v, int k) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
 }
 template <bool TOP>
 __device__ __forceinline__ void emit_targets_lanes(const ThrDev &pd, const TgtLanes &tl, int nt, int &k, int &next_rank,
-                                                   int step, int best, int prev, const RowFlags &rf, double *orow) {
+                                                   int step, int best, int prev, const RowFlags &rf, double *orow,
+                                                   bool store = true) {
   int kk = __builtin_amdgcn_readfirstlane(k);
   int rank_k = step;
   do {
@@ -703,7 +732,7 @@ __device__ __forceinline__ void emit_targets_lanes(const ThrDev &pd, const TgtLa
     qp.pad = 0;
     qp.w_lo = readlane_f64(tl.w_lo, kk);
     qp.w_hi = readlane_f64(tl.w_hi, kk);
-    orow[size_t(p) * pd.n_doy] = finish_quantile(qp, lo, hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
+    if (store) orow[size_t(p) * pd.n_doy] = finish_quantile(qp, lo, hi, rf.n_pos < 0, rf.n_pos, rf.n_neg, pd.n);
     ++kk;
     rank_k = kk < nt ? __builtin_amdgcn_readlane(tl.rank, min(kk, 63)) : -1;
   } while (rank_k == step);
@@ -906,7 +935,7 @@ template <int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
                                                 const float *tail_cur, const uint32_t *flags, const uint16_t *cl, int r,
                                                 double *orow, const TgtLanes &tl_top, const TgtLanes &tl_bot,
-                                                int prio_phase = -1, int which = 0 /* 0: both walks, 1: top, 2: bottom */) {
+                                                int prio_phase = -1) {
   RowFlags rf{0, 0};
   uint32_t nan_or = 0;
 #pragma unroll
@@ -917,9 +946,226 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
     rf.n_neg += f & 0x7fff;
   }
   if (nan_or >> 31) rf.n_pos = -1;
-  if (which != 2) merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_top, prio_phase);
-  if (which != 1) merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_bot, prio_phase);
+  merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_top, prio_phase);
+  merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_bot, prio_phase);
   if (prio_phase >= 0) __builtin_amdgcn_s_setprio(3);
+}
+
+// ---- segmented walks: enter the W-way merge at a pivot ----------------------------------------------------------------
+// A multiway merge can be entered at ANY value v, not only at an end of the window: if c_j is the number of column j's
+// samples ranked before v, the heads (c_0 .. c_W-1) are exactly the merge state after C = sum c_j pops -- whatever v is, as
+// long as every sample before it counts and none after it does.  So a walk whose first requested rank R1 lies deep does
+// not start at rank 0: the lane takes v = the p-th sample of the window's centre column (p chosen on the host so that C
+// falls a few standard deviations short of R1), finds every c_j by a stride descent in the sorted LDS column (7 probes
+// per column, all columns in flight together), builds its heads there and walks on from rank C.  A plan's ranks are cut
+// into runs (ThrSeg) at the large gaps between them; every run has its own merging wave per 64 rows and its own strips,
+// so the chains are short AND parallel (the median set: ~250 steps instead of 817; ranks spread over the whole window:
+// six chains of ~150 instead of two of 750).  Exactness never depends on the pivot: only the length of the walk does.  If a
+// lane's C overshoots (more than `limit` samples before the pivot, so the run's first rank would be missed) the wave
+// takes a shallower pivot, at worst none (C = 0).  Lanes start from different ranks C; the wave counts ranks from the
+// smallest and a lane joins in when the count reaches its own, so emissions stay wave-uniform.
+template <bool TOP, int NG, int ROWS>
+__device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg, const int2 *tgt, const unsigned char *image,
+                                              unsigned char *strips, const uint16_t *cl, int r, const RowFlags &rf,
+                                              double *orow, bool store, const TgtLanes &tl) {
+  static_assert(NG >= 1 && NG <= 4, "group id is two payload bits");
+  const int steps = sg.steps, nt = sg.nt;
+  if (steps == 0) return;
+  auto better = [](double a, double b) { return TOP ? pk_max(a, b) : pk_min(a, b); };
+  auto worse = [](double a, double b) { return TOP ? pk_min(a, b) : pk_max(a, b); };
+  auto head = [](uint32_t bits, uint32_t pay) { return __hiloint2double(int(bits), int(pay)); };
+  // merge order of two samples (raw float bits, sentinels included): the order of the doubles they are the high words of
+  auto before = [](uint32_t k, uint32_t v) {  // k is popped before v by this walk (strictly)
+    const double a = __hiloint2double(int(k), 0), b = __hiloint2double(int(v), 0);
+    return TOP ? a > b : a < b;
+  };
+  const int rp = pd.RP;  // strip pitch of a segmented plan: the block's rows rounded up to 64 (not the ROWS of the classic form)
+  unsigned char *const sA = strips + size_t(r) * 16;
+  unsigned char *const sB = strips + size_t(NG) * rp * 16 + size_t(r) * 8;
+  const uint32_t img0 = uint32_t(reinterpret_cast<uintptr_t>(image));
+  const int S = pd.S, W = pd.W;
+  uint32_t cbase[4 * NG];  // LDS byte address of slot 0 of every window column (padding entries: the pseudo column)
+  {
+    const uint4 *cl4 = reinterpret_cast<const uint4 *>(cl);
+#pragma unroll
+    for (int v4 = 0; v4 < NG / 2 + (NG & 1); ++v4) {
+      uint32_t wv[4];
+      if (NG == 1) {
+        const uint2 h = *reinterpret_cast<const uint2 *>(cl);
+        wv[0] = h.x; wv[1] = h.y; wv[2] = wv[3] = 0;
+      } else {
+        const uint4 q4 = cl4[v4];
+        wv[0] = q4.x; wv[1] = q4.y; wv[2] = q4.z; wv[3] = q4.w;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j0 = v4 * 8 + 2 * u;
+        if (j0 < 4 * NG) cbase[j0] = img0 + uint32_t(int(wv[u] & 0xffffu) * pd.img_pitch) * 4u;
+        if (j0 + 1 < 4 * NG) cbase[j0 + 1] = img0 + uint32_t(int(wv[u] >> 16) * pd.img_pitch) * 4u;
+      }
+    }
+  }
+  // ---- entry: slot of every column's first head, and the rank C the lane starts from
+  uint32_t start[4 * NG];
+  int C = 0;
+  {
+    int p = sg.pivot_pos;  // wave-uniform
+    while (true) {
+#pragma unroll
+      for (int j = 0; j < 4 * NG; ++j) start[j] = uint32_t(TOP ? 1 : S);
+      C = 0;
+      if (p <= 0) break;
+      // pivot: the MEAN of the window columns' p-th samples counted from the walk's own end (any value will do; one
+      // column's p-th sample sits at a quantile level that is off by sqrt(p (S - p) / S) / S -- +-68 ranks of the window at
+      // p = 38 of 100, measured as entry ranks 204 .. 441 inside one wave -- the mean of fifteen is four times closer).
+      // An infinite or overflowing mean is still a valid pivot (nothing or everything ranks before it).
+      uint32_t v;
+      {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4 * NG; ++j)
+          if (j < W) acc += __uint_as_float(lds_u32(cbase[j] + uint32_t(TOP ? p : S + 1 - p) * 4u));
+        acc *= 1.0f / float(W);
+        v = __float_as_uint(acc);
+        if (acc != acc) v = TOP ? kRawMax : kRawMin;   // +inf and -inf in one window: enter at the end instead
+      }
+      // pos_j = samples of column j ranked before v, by descent in strides from the column's own end.  The columns are
+      // sorted descending: slot 1 the largest, slot S the smallest, sentinels at 0 and S + 1 (never "before" anything).
+      //   TOP: pos_j counts from slot 1 down;  bottom: pos_j counts from slot S up (slot S + 1 - idx).
+      uint32_t pos[4 * NG];
+#pragma unroll
+      for (int j = 0; j < 4 * NG; ++j) pos[j] = 0;
+      for (int stride = 64; stride >= 1; stride >>= 1) {  // S <= 100 in this kernel: 7 strides reach 127
+        uint32_t idx[4 * NG], k[4 * NG];
+#pragma unroll
+        for (int j = 0; j < 4 * NG; ++j) {
+          idx[j] = min(pos[j] + uint32_t(stride), uint32_t(S + 1));
+          k[j] = lds_u32(cbase[j] + (TOP ? idx[j] : uint32_t(S + 1) - idx[j]) * 4u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4 * NG; ++j) pos[j] = before(k[j], v) ? idx[j] : pos[j];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4 * NG; ++j) {
+        if (j < W) {
+          C += int(pos[j]);
+          start[j] = TOP ? pos[j] + 1u : uint32_t(S) - pos[j];
+        }
+      }
+      if (__ballot(C > sg.limit) == 0) break;  // every lane can still emit the run's first rank (with its predecessor)
+      p -= max(2, p >> 3);                     // some lane overshot: a slightly shallower pivot for the whole wave
+    }
+  }
+  double m[NG];
+  {
+    uint32_t pos[4 * NG], kb[4 * NG];
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) pos[j] = cbase[j] + start[j] * 4u;
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) kb[j] = lds_u32(pos[j]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      double hd[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hd[i] = head(kb[4 * g + i], pos[4 * g + i] | uint32_t(g));
+      sort_best_first<TOP, 4>(hd);
+      *reinterpret_cast<double2 *>(sA + g * (rp * 16)) = make_double2(hd[1], hd[2]);
+      *reinterpret_cast<double *>(sB + g * (rp * 8)) = hd[3];
+      m[g] = hd[0];
+    }
+    sort_best_first<TOP, NG>(m);
+  }
+  // wave-wide range of the entry ranks (every lane of a merging wave runs a merge: reductions over all 64 lanes)
+  int c_min = C, c_max = C;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    c_min = min(c_min, __shfl_xor(c_min, d, 64));
+    c_max = max(c_max, __shfl_xor(c_max, d, 64));
+  }
+  c_min = __builtin_amdgcn_readfirstlane(c_min);
+  c_max = __builtin_amdgcn_readfirstlane(c_max);
+  if (HDP_DBG(pd, 2048) && (threadIdx.x & 63) == 0) {  // entry statistics of the segmented walks
+    atomicAdd(&pd.clk[24], (unsigned long long)c_min);
+    atomicAdd(&pd.clk[25], (unsigned long long)c_max);
+    atomicAdd(&pd.clk[26], (unsigned long long)sg.limit);
+    atomicAdd(&pd.clk[27], 1ull);
+  }
+
+  int k = 0;
+  int next_rank = nt > 0 ? (tl.ok ? __builtin_amdgcn_readlane(tl.rank, 0) : ldk(&tgt[0]).x) : -1;
+  double prev = head(TOP ? kRawMin : kRawMax, 0);
+  uint32_t nk, lo_cur, aA, aB;
+  double2 h12;
+  double h3;
+  const uint32_t sA0 = uint32_t(reinterpret_cast<uintptr_t>(sA)), sB0 = uint32_t(reinterpret_cast<uintptr_t>(sB));
+  typedef double v2f64 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v2f64 *lds_d2;
+  typedef __attribute__((address_space(3))) double *lds_d1;
+  auto issue = [&](double top) {
+    lo_cur = uint32_t(__double2loint(top));
+    const uint32_t g = lo_cur & 3u;
+    aB = __umul24(g, uint32_t(rp * 8)) + sB0;
+    aA = __umul24(g, uint32_t(rp * 16)) + sA0;
+    nk = lds_u32((lo_cur & 0x3fffcu) + (TOP ? 4u : uint32_t(-4)));
+    const v2f64 t = *reinterpret_cast<lds_d2>(uintptr_t(aA));
+    h12 = make_double2(t.x, t.y);
+    h3 = *reinterpret_cast<lds_d1>(uintptr_t(aB));
+  };
+  auto do_step = [&]() {  // as merge_row_lean's (untiered)
+    const uint32_t pay = lo_cur + (TOP ? 4u : uint32_t(-4));
+    const double fresh = head(nk, pay);
+    const double t0 = better(fresh, h12.x);
+    const double w1 = worse(fresh, h12.x);
+    const double b1 = better(w1, h12.y);
+    const double w2 = worse(w1, h12.y);
+    const double b2 = better(w2, h3);
+    const double b3 = worse(w2, h3);
+    *reinterpret_cast<lds_d2>(uintptr_t(aA)) = v2f64{b1, b2};
+    *reinterpret_cast<lds_d1>(uintptr_t(aB)) = b3;
+    double m0n = t0;
+    if constexpr (NG >= 2) m0n = better(t0, m[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(m0n);
+    __builtin_amdgcn_sched_barrier(0);
+    m[0] = m0n;
+    if constexpr (NG >= 2) {
+      double w = worse(t0, m[1]);
+#pragma unroll
+      for (int i = 1; i + 1 < NG; ++i) {
+        const double nb = better(w, m[i + 1]);
+        w = worse(w, m[i + 1]);
+        m[i] = nb;
+      }
+      m[NG - 1] = w;
+    }
+  };
+  issue(m[0]);
+  // ranks c_min .. c_max - 1: lanes join in as the count reaches their entry rank (no requested rank lies here:
+  // every lane has C <= limit < the run's first rank)
+  int step = c_min;
+  for (; step < c_max; ++step) {
+    if (step >= C) {
+      prev = m[0];
+      do_step();
+    }
+  }
+  while (true) {
+    const int stop = (next_rank >= 0 && next_rank < steps) ? next_rank : steps;  // wave-uniform
+    if (step < stop) {
+      for (; step < stop - 1; ++step) do_step();
+      prev = m[0];
+      do_step();
+      ++step;
+    }
+    if (step >= steps) break;
+    if (tl.ok)  // wave-uniform
+      emit_targets_lanes<TOP>(pd, tl, nt, k, next_rank, step, __double2hiint(m[0]), __double2hiint(prev), rf, orow, store);
+    else
+      emit_targets<TOP, true>(pd, tgt, nt, k, next_rank, step, __double2hiint(m[0]), __double2hiint(prev), rf, store, orow);
+    next_rank = __builtin_amdgcn_readfirstlane(next_rank);
+  }
 }
 
 // ---- rank selection (many samples per column) ---------------------------------------------------
@@ -1315,9 +1561,10 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   const int flags_pitch = ((pd.ncols_max * 4 + 15) & ~15) >> 2;
   off += 2 * size_t(flags_pitch) * 4;
   unsigned char *strips = smem + off;  // merge heads: 2nd..4th of every (group, row), see merge_row_lean
-  constexpr bool kCanDual = ROWS == kLeanRows;  // the whole-cell form never splits the walks: nothing of this in its code
-  const bool dual = kCanDual && pd.dual != 0;
-  off += lean_strip_bytes<NG, ROWS>() * (dual ? 2 : 1);  // dual: one set per walk direction
+  constexpr bool kCanSeg = ROWS == kLeanRows;  // the whole-cell form never cuts its walks into runs: nothing of this in its code
+  const int n_segs = kCanSeg ? pd.n_segs : 0;
+  const size_t seg_strip_bytes = size_t(NG) * size_t(pd.RP) * 24;  // segmented: one set of strips per run, pitch = rows rounded to 64
+  off += n_segs > 0 ? seg_strip_bytes * size_t(n_segs) : lean_strip_bytes<NG, ROWS>();
   uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][4 * NG] local columns of this block's windows (slots past W: the pseudo column)
 
   const int nb = pd.n_blocks;
@@ -1371,12 +1618,11 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   if (producer) __builtin_amdgcn_s_setprio(0);
   else __builtin_amdgcn_s_setprio(3);
   const int pw = rank - n_merge;      // producer index
-  // merging waves: row of the block this lane merges.  Dual form (both walks long): the first half of the merging waves
-  // walks the rows down from the top, the second half walks the same rows up from the bottom, each with its own strips --
-  // two chains of half the length per row instead of one.
-  const int nm_rows = dual ? (n_merge >> 1) : n_merge;
-  const int walk = dual ? (rank < nm_rows ? 1 : 2) : 0;
-  const int mrow = (dual ? (rank % max(nm_rows, 1)) : rank) * 64 + lane;
+  // merging waves: row of the block this lane merges.  Segmented plans: merging wave `rank` walks run rank / nm_rows of
+  // the rows (rank % nm_rows) * 64 .. + 63, with the run's own strips.
+  const int nm_rows = n_segs > 0 ? max(n_merge / n_segs, 1) : n_merge;
+  const int seg = n_segs > 0 ? rank / nm_rows : 0;
+  const int mrow = (n_segs > 0 ? rank % nm_rows : rank) * 64 + lane;
 
   // Two loops, one per role, with the same two barriers per item ("image free / keys sorted", "image written"):
   // s_barrier counts wave arrivals, so waves may reach it from different code.  Written as one loop, the sorted keys
@@ -1520,24 +1766,59 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
     }
   } else {
     const TgtLanes tl_top = load_tgt_lanes<true>(pd, lane), tl_bot = load_tgt_lanes<false>(pd, lane);
+    // segmented plans: this wave's run and its emission table
+    ThrSeg sg{};
+    const int2 *sg_tgt = nullptr;
+    TgtLanes tl_seg{-1, 0, 0, 0.0, 0.0, false};
+    if constexpr (kCanSeg) {
+      if (n_segs > 0) {
+        const ThrSeg *sp = pd.segs + seg;  // wave-uniform: scalar loads
+        sg.top = int(ldk64(sp)); sg.pivot_pos = int(ldk64(sp) >> 32);
+        sg.limit = int(ldk64(reinterpret_cast<const char *>(sp) + 8)); sg.tgt_off = int(ldk64(reinterpret_cast<const char *>(sp) + 8) >> 32);
+        sg.nt = int(ldk64(reinterpret_cast<const char *>(sp) + 16)); sg.steps = int(ldk64(reinterpret_cast<const char *>(sp) + 16) >> 32);
+        sg_tgt = (sg.top ? pd.tgt_top : pd.tgt_bot) + sg.tgt_off;
+        tl_seg = load_tgt_lanes_seg(pd, sg_tgt, sg.nt, lane);
+      }
+    }
     for (int64_t s = 0; s <= n_items; ++s) {
       const uint32_t *flags_m = flags0 + int((s + 1) & 1) * flags_pitch;  // census of block s - 1
       unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
       const bool clocked = HDP_DBG(pd, 32) && lane == 0 && rank == 0;
       const bool clocked_w = HDP_DBG(pd, 1024) && lane == 0;
       if (clocked || clocked_w) c0 = __builtin_readcyclecounter();
-      if (s >= 1 && mrow < nrows) {
+      if (kCanSeg && n_segs > 0) {
+        if constexpr (kCanSeg) {
+          // Every lane of a segmented merging wave runs a merge (lanes past the block's last row repeat that row without
+          // storing): the entry ranks are reduced over all 64 lanes.
+          if (s >= 1 && mrow < nm_rows * 64) {
+            const int64_t cell = first_cell + (s - 1) * wg_per_blk;
+            const int rr = min(mrow, nrows - 1);
+            const uint16_t *cl = cl_lds + rr * (4 * NG);
+            double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row0 + rr;  // [cell][P][n_doy]
+            RowFlags rf{0, 0};
+            uint32_t nan_or = 0;
+#pragma unroll
+            for (int j = 0; j < 4 * NG; ++j) {
+              const uint32_t f = (j < pd.W) ? flags_m[cl[j]] : 0u;
+              nan_or |= f;
+              rf.n_pos += (f >> 15) & 0x7fff;
+              rf.n_neg += f & 0x7fff;
+            }
+            if (nan_or >> 31) rf.n_pos = -1;
+            unsigned char *st = strips + size_t(seg) * seg_strip_bytes;
+            if (sg.top)
+              merge_row_seg<true, NG, ROWS>(pd, sg, sg_tgt, reinterpret_cast<const unsigned char *>(colbuf), st, cl, mrow, rf, orow, mrow < nrows, tl_seg);
+            else
+              merge_row_seg<false, NG, ROWS>(pd, sg, sg_tgt, reinterpret_cast<const unsigned char *>(colbuf), st, cl, mrow, rf, orow, mrow < nrows, tl_seg);
+          }
+        }
+      } else if (s >= 1 && mrow < nrows) {
         const int64_t cell = first_cell + (s - 1) * wg_per_blk;
         const int row = row0 + mrow;
         const uint16_t *cl = cl_lds + mrow * (4 * NG);
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
 #if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 1))
         // ranks >= 4 are the second merging wave of their SIMD (roles above: one merging wave per SIMD first)
-        if constexpr (kCanDual)
-          merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf),
-                              strips + (walk == 2 ? lean_strip_bytes<NG, ROWS>() : 0),
-                              tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow, tl_top, tl_bot, -1, walk);
-        else
           merge_both_lean<NG, TIER, ROWS>(pd, reinterpret_cast<const unsigned char *>(colbuf), strips,
                               tail_wg + size_t((s + 1) & 1) * tail_half, flags_m, cl, mrow, orow, tl_top, tl_bot,
                               n_merge > 4 ? int(rank >= 4) : -1);
@@ -1790,7 +2071,7 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
              "thresholds_lane_kernel<N=%d,NG=%d%s> (one lane per column: register merge-exchange sort; %d merging waves; "
              "%d rows x %d blocks, %zu B LDS%s)",
              plan->lane_n, std::max(2, plan->Wp >> 2),
-             plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : (plan->n_blocks == 1 && plan->RP > hdp::kLeanRows ? ",whole-cell" : (plan->lane_dual ? ",dual" : "")), plan->lane_n_merge,
+             plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : (plan->n_blocks == 1 && plan->RP > hdp::kLeanRows ? ",whole-cell" : (plan->lane_n_segs > 0 ? ",segmented" : "")), plan->lane_n_merge,
              plan->rows_per_block, plan->n_blocks, plan->lane_lds_bytes,
              plan->lane_tier_k < plan->S ? "; top 60 samples of a column in LDS, the rest in a global tail" : "");
   else
@@ -1837,7 +2118,8 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.nt_bot = plan->nt_bot;
   pd.n = (int)plan->n;
   pd.n_merge = plan->n_merge;
-  pd.dual = 0;
+  pd.n_segs = 0;
+  pd.segs = nullptr;
   pd.tixl = plan->tixl.as<int32_t>();
   pd.blk_tixl_off = plan->blk_tixl_off.as<int32_t>();
   pd.tier_k = plan->lane_tier_k;
@@ -1851,7 +2133,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.debug = 0;
 #endif
   pd.clk = nullptr;
-  if (pd.debug & (8 | 32 | 1024)) {
+  if (pd.debug & (8 | 32 | 1024 | 2048)) {
     if (plan->clk.bytes == 0) {
       HDP_HIP_TRY(plan->clk.alloc(32 * sizeof(unsigned long long)));
       HDP_HIP_TRY(hipMemset(plan->clk.p, 0, 32 * sizeof(unsigned long long)));
@@ -1865,7 +2147,8 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   if (g_reserve_only && !var.lane) return HDP_OK;
   if (var.lane) {
     pd.n_merge = plan->lane_n_merge;
-    pd.dual = plan->lane_dual ? 1 : 0;
+    pd.n_segs = plan->lane_n_segs;
+    pd.segs = plan->lane_segs.as<hdp::ThrSeg>();
     switch (plan->lane_n) {
       case 16: return launch_thr_lane<16>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
       case 32: return launch_thr_lane<32>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
@@ -2189,6 +2472,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   }
   pl->lane = lane;
   pl->lane_n = lane_n;
+  std::vector<hdp::ThrSeg> lane_segs_host;  // segmented blocked form: the runs chosen below
   if (lane) {
     // Tiered image: the merge is a chain of dependent steps per row, so the kernel's throughput is the number of rows
     // resident per CU over the step latency, and the rows are bounded by LDS.  With more than 64 samples per column
@@ -2208,37 +2492,94 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     b += (size_t(rows) * 4 * ngw * 2 + 15) & ~size_t(15);
     pl->lane_lds_bytes = whole ? whole_lds : b;
     if (!whole && (b > kMaxLds || rows > hdp::kLeanRows)) pl->lane = false;
-    // Dual form of the blocked kernel: when BOTH walks are long (quantile sets that reach deep from both ends of the
-    // window) a row's descending and ascending merge run on two different waves, each with its own head strips -- two
-    // chains of half the length, and the kernel is bound by the length of its chains.  Blocks shrink until two
-    // workgroups (each with twice the merging waves and twice the strips) still share a CU.  HDP_THR_DUAL=0 / 1.
-    const long long dual_opt = hdp::env_option("HDP_THR_DUAL", -1);
-    const bool dual_want = dual_opt > 0 || (dual_opt < 0 && pl->steps_top >= 96 && pl->steps_bot >= 96);
-    if (pl->lane && !whole && !rows_forced && dual_want && pl->steps_top > 0 && pl->steps_bot > 0) {
-      const int tpw = hdp::lane_tasks_per_wave_rt(lane_n);
-      for (int r = std::min(rows, (int)hdp::kLeanRows); r >= 16; --r) {
-        const int nb = int((n_doy + r - 1) / r);
-        const int rb = int((n_doy + nb - 1) / nb);  // balanced blocks
-        int c2 = 0;
-        if (max_lds_for_rows(rb, &c2) > kMaxLds) continue;
-        const int nm2 = 2 * ((rb + 63) / 64);
-        const int n_tasks = (c2 + 63) / 64;
-        if (nm2 + (n_tasks + tpw - 1) / tpw > hdp::kThrThreads / 64) continue;
-        size_t bd = (size_t(c2 + 1) * ip * 4 + 15) & ~size_t(15);
-        bd += 2 * ((size_t(c2) * 4 + 15) & ~size_t(15));
-        bd += 2 * size_t(ngw) * hdp::kLeanRows * 24;
-        bd += (size_t(rb) * 4 * ngw * 2 + 15) & ~size_t(15);
-        if (bd > (kMaxLds + 1024) / 2 - 512) continue;  // two workgroups per CU
-        rows = rb;
-        cm = c2;
-        pl->lane_dual = true;
-        pl->lane_lds_bytes = bd;
-        break;
+    // Segmented form of the blocked kernel (round 4; the round-3 "dual" form was its two-run case without pivots): the
+    // requested ranks of each direction are cut into runs at the gaps between them; every run gets its own merging waves
+    // and head strips and enters the merge at a pivot a few standard deviations short of its first rank (merge_row_seg), so
+    // a row's chains are short and run side by side.  Blocks shrink until the workgroup (runs x ceil(rows / 64) merging
+    // waves + producers) still has 8 waves and two workgroups share a CU.  HDP_THR_DUAL=0: never; 1: whenever it fits.
+    const long long seg_opt = hdp::env_option("HDP_THR_DUAL", -1);
+    if (pl->lane && !whole && !rows_forced && seg_opt != 0) {
+      constexpr int kMaxSegs = 6, kSplitGap = 64, kMinEntry = 64;
+      struct Run { int top; size_t first, count; };   // targets [first, first + count) of `top` or `bot`
+      std::vector<Run> runs;
+      auto cut = [&](const std::vector<Tgt> &v, int is_top) {
+        for (size_t i = 0; i < v.size(); ++i) {
+          if (i == 0 || v[i].rank - v[i - 1].rank > kSplitGap) runs.push_back({is_top, i, 1});
+          else runs.back().count += 1;
+        }
+      };
+      cut(top, 1);
+      cut(bot, 0);
+      auto gap_before = [&](size_t k) {  // ranks a run made of runs k - 1 and k would span (same direction), else "infinite"
+        if (k == 0 || runs[k].top != runs[k - 1].top) return 1 << 30;
+        const std::vector<Tgt> &v = runs[k].top ? top : bot;
+        return v[runs[k].first + runs[k].count - 1].rank - v[runs[k - 1].first].rank;
+      };
+      while ((int)runs.size() > kMaxSegs) {  // too many runs for the workgroup: join the two neighbours that make the shortest run
+        size_t best = 0;
+        int bg = 1 << 30;
+        for (size_t k = 1; k < runs.size(); ++k)
+          if (gap_before(k) < bg) { bg = gap_before(k); best = k; }
+        if (bg == (1 << 30)) break;
+        runs[best - 1].count += runs[best].count;
+        runs.erase(runs.begin() + best);
+      }
+      std::vector<hdp::ThrSeg> segs;
+      bool any_pivot = false;
+      for (const Run &r : runs) {
+        const std::vector<Tgt> &v = r.top ? top : bot;
+        hdp::ThrSeg sg{};
+        sg.top = r.top;
+        sg.tgt_off = (int32_t)r.first;
+        sg.nt = (int32_t)r.count;
+        sg.steps = v[r.first + r.count - 1].rank + 1;
+        const int R1 = v[r.first].rank;
+        sg.limit = R1 - 1;
+        sg.pivot_pos = 0;
+        if (R1 >= kMinEntry) {
+          // the p-th sample of one column ranks about W * p in the window; its count C is binomial-like: leave four
+          // standard deviations plus two samples per column of head room below the run's first rank
+          // C = samples before the mean of the W columns' p-th samples: binomial-like count noise R1 (1 - R1 / n) plus the
+          // pivot's own quantile-level noise, (W - 1) S sqrt(p (S - p) / S^3 / W) ranks
+          const double pl0 = double(R1) / double(W), Sd = double(S);
+          const double sd_count = std::sqrt(double(R1) * (1.0 - double(R1) / double(n)));
+          const double sd_pivot = double(W - 1) * Sd * std::sqrt(std::max(pl0 * (Sd - pl0), 0.0) / (Sd * Sd * Sd) / double(W));
+          const double sd = std::sqrt(sd_count * sd_count + sd_pivot * sd_pivot);
+          const int pp = int((double(R1) - 3.5 * sd - double(W)) / double(W));
+          if (pp >= 2) sg.pivot_pos = (int32_t)std::min<int64_t>(pp, S - 1);
+        }
+        any_pivot |= sg.pivot_pos > 0;
+        segs.push_back(sg);
+      }
+      const bool both_long = pl->steps_top >= 96 && pl->steps_bot >= 96;   // the old dual condition
+      if ((int)segs.size() <= kMaxSegs && !segs.empty() && (seg_opt > 0 || any_pivot || (both_long && segs.size() >= 2))) {
+        const int tpw = hdp::lane_tasks_per_wave_rt(lane_n);
+        const int ns = (int)segs.size();
+        for (int r = std::min(rows, (int)hdp::kLeanRows); r >= 16; --r) {
+          const int nb = int((n_doy + r - 1) / r);
+          const int rb = int((n_doy + nb - 1) / nb);  // balanced blocks
+          int c2 = 0;
+          if (max_lds_for_rows(rb, &c2) > kMaxLds) continue;
+          const int nm2 = ns * ((rb + 63) / 64);
+          const int n_tasks = (c2 + 63) / 64;
+          if (nm2 + (n_tasks + tpw - 1) / tpw > hdp::kThrThreads / 64) continue;
+          size_t bd = (size_t(c2 + 1) * ip * 4 + 15) & ~size_t(15);
+          bd += 2 * ((size_t(c2) * 4 + 15) & ~size_t(15));
+          bd += size_t(ns) * size_t(ngw) * size_t((rb + 63) & ~63) * 24;
+          bd += (size_t(rb) * 4 * ngw * 2 + 15) & ~size_t(15);
+          if (bd > (kMaxLds + 1024) / 2 - 512 && !(ns > 2 && bd <= kMaxLds)) continue;  // two workgroups per CU (one when many runs)
+          rows = rb;
+          cm = c2;
+          pl->lane_n_segs = ns;
+          lane_segs_host = segs;
+          pl->lane_lds_bytes = bd;
+          break;
+        }
       }
     }
   }
   pl->n_merge = (rows + 63) / 64;
-  pl->lane_n_merge = pl->lane_dual ? 2 * pl->n_merge : pl->n_merge;
+  pl->lane_n_merge = pl->lane_n_segs > 0 ? pl->lane_n_segs * pl->n_merge : pl->n_merge;
   pl->rows_per_block = rows;
   pl->RP = (rows + 63) & ~63;
   pl->ncols_max = cm;
@@ -2383,6 +2724,7 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   up(pl->qparam, qp.data(), qp.size() * sizeof(hdp::QuantileParam));
   up(pl->tgt_top, ttop.data(), ttop.size() * sizeof(int2));
   up(pl->tgt_bot, tbot.data(), tbot.size() * sizeof(int2));
+  if (!lane_segs_host.empty()) up(pl->lane_segs, lane_segs_host.data(), lane_segs_host.size() * sizeof(hdp::ThrSeg));
   if (pl->lane) {
     // per block [N][64 * tasks]: BYTE offset of sample s of local column c (pad lanes repeat the last column)
     std::vector<int32_t> tl, tloff;
@@ -2430,7 +2772,10 @@ extern "C" int hdp_threshold_plan_reserve(hdp_threshold_plan *plan, int64_t n_ce
 extern "C" int hdp_threshold_plan_destroy(hdp_threshold_plan *plan) {
   if (plan && plan->clk.bytes) {  // HDP_THR_DEBUG=8: per-phase clocks of the lead wave, summed over blocks
     unsigned long long c[32] = {0};
-    if (hipMemcpy(c, plan->clk.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && c[3] && c[8]) {
+    if (hipMemcpy(c, plan->clk.p, sizeof c, hipMemcpyDeviceToHost) == hipSuccess && c[27])
+      fprintf(stderr, "[hdp thresholds segmented] walks=%llu  mean entry rank: lowest lane %.1f, highest lane %.1f; mean limit %.1f\n",
+              c[27], double(c[24]) / c[27], double(c[25]) / c[27], double(c[26]) / c[27]);
+    if (c[3] && c[8]) {
       fprintf(stderr, "[hdp thresholds lane] items=%llu  busy ticks/item by wave rank (mergers first, then producers):", c[3]);
       for (int r = 0; r < 12; ++r) fprintf(stderr, " %.0f", double(c[8 + r]) / c[3]);
       fprintf(stderr, "  | mean SIMD of merging ranks:");

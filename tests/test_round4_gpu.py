@@ -71,3 +71,60 @@ def test_rccl_version_and_mapped_runtime_are_reported():
     assert info["rccl_version"] > 20000
     for key in ("librccl", "libamdhip64", "libhsa-runtime64"):
         assert info["mapped"][key], info
+
+
+# ---- thresholds: quantile SETS anywhere in [0, 1] (the former tools/dbg/fuzz_thresholds.py) -----------------------------
+@pytest.mark.parametrize("seed", range(48))
+def test_threshold_plans_fuzz_quantile_sets(seed, monkeypatch):
+    """Random record lengths, window radii and quantile sets (tails, straddling the median, spread over the window, both
+    tails, duplicates, 0 and 1), ties and special values -- the plan's own choice, its blocked form with the walks cut into
+    runs that enter the merge at a pivot (HDP_THR_DUAL=1 forces the runs), and the classic blocked form, against the C
+    oracle, bit for bit."""
+    from hdp_amd import calendar as cal
+    from oracle import c_oracle, hdp_oracle as orc
+    rng = np.random.default_rng(50000 + seed)
+    years = int(rng.choice([3, 9, 17, 40, 64, 65, 80, 100, 100, 100, 128]))
+    dates = orc.noleap_date_range("0001-01-01", f"{years:04d}-12-31")
+    T = dates.size
+    radius = int(rng.choice([0, 1, 3, 7, 7, 7, 8]))
+    kind = int(rng.integers(0, 6))
+    P = int(rng.integers(1, 13))
+    if kind == 0:
+        q = np.sort(rng.uniform(0.85, 1.0, P))
+    elif kind == 1:
+        q = np.sort(rng.uniform(0.0, 0.15, P))
+    elif kind == 2:
+        q = np.sort(rng.uniform(0.4, 0.6, P))
+    elif kind == 3:
+        q = np.sort(rng.uniform(0.0, 1.0, P))
+    elif kind == 4:
+        q = np.sort(np.concatenate([rng.uniform(0.0, 0.1, P // 2 + 1), rng.uniform(0.9, 1.0, P // 2 + 1)]))
+    else:
+        q = np.sort(rng.choice([0.0, 0.5, 1.0, 0.25, 0.75, 0.5000001, 0.4999999], P))
+    ncell = int(rng.integers(1, 6))
+    x = (15 + 6 * np.sin(2 * np.pi * np.arange(T) / 365.0)[None, :] + rng.normal(0, 2, size=(ncell, T))).astype(np.float32)
+    if rng.random() < 0.3:
+        x = np.round(x)                          # many exact ties
+    if rng.random() < 0.2:
+        x[0, rng.integers(0, T, 3)] = np.inf
+    if rng.random() < 0.2:
+        x[0, rng.integers(0, T, 3)] = -np.inf
+    if rng.random() < 0.1:
+        x[-1, rng.integers(0, T)] = np.nan
+    if rng.random() < 0.15:
+        x[ncell // 2] = np.float32(3.25)         # a constant series: every sample ties with the pivot
+    ti, cols = cal.window_columns(dates, radius)
+    win = cal.expand_window_table(ti, cols)
+    with np.errstate(invalid="ignore"):
+        want = c_oracle.thresholds(x, win, q)
+
+    def same(a, b):
+        return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+    for env in ({}, {"HDP_THR_WHOLE": "0"}, {"HDP_THR_WHOLE": "0", "HDP_THR_DUAL": "1"}, {"HDP_THR_WHOLE": "0", "HDP_THR_DUAL": "0"}):
+        for k in ("HDP_THR_WHOLE", "HDP_THR_DUAL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = core.compute_percentiles(x, ti, cols, q)
+        assert same(got, want), (env, years, radius, kind, q)

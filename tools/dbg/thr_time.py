@@ -19,6 +19,8 @@ T = years * 365 * members
 dates = utils.noleap_date_range("2000-01-01", f"{2000 + years - 1}-12-31")
 ti, cols = cal.window_columns(np.concatenate([dates] * members), 7)
 q = np.arange(0.9, 1.0, 0.01) if members == 1 else np.linspace(0.80, 0.99, 20)
+if os.environ.get('HDP_QSET') == 'median': q = np.linspace(0.455, 0.545, 10)
+if os.environ.get('HDP_QSET') == 'spread': q = np.linspace(0.05, 0.95, 10)
 plan = core.ThresholdPlan(ti, cols, q, T)
 print(plan.describe() if hasattr(plan, "describe") else "")
 x = torch.empty(n * T, dtype=torch.float32, device=dev)
