@@ -128,3 +128,82 @@ def test_threshold_plans_fuzz_quantile_sets(seed, monkeypatch):
             monkeypatch.setenv(k, v)
         got = core.compute_percentiles(x, ti, cols, q)
         assert same(got, want), (env, years, radius, kind, q)
+
+
+@pytest.mark.timeout(1500)
+def test_c5_full_grid_192x288_cells_x_10_members():
+    """BASELINE config 5 at its full single-GPU size: thresholds of all 55 296 cells from the ten members concatenated along
+    time (threshold.py:114-119: S = 1000, 80.7 GB of input), then -- the baseline freed -- the metrics of all 552 960 member
+    series (20 percentiles x 12 definitions, 106 GB of int16 results).  Properties over EVERY cell and series, computed on
+    the device in slabs; C-oracle equality on 64 cells strided over both hemispheres."""
+    import torch
+    from hdp_amd import calendar as cal, utils
+    from oracle import c_oracle
+    lib = _lib.ensure_device()
+    dev = torch.device("cuda", 0)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b < 235 * (1 << 30):
+        pytest.skip("needs ~230 GiB of free HBM")
+    ts = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(ts)
+    stream = ts.cuda_stream
+    years, M, n = 100, 10, 192 * 288
+    PERC = np.linspace(0.80, 0.99, 20)
+    DEFS = [[d, b, b] for d in (3, 4, 5, 6) for b in (0, 1, 2)]
+    dates = utils.noleap_date_range("2000-01-01", f"{2000 + years - 1}-12-31")
+    T = dates.size
+    ti, cols = cal.window_columns(np.concatenate([dates] * M), 7)
+    dm = cal.build_doy_map(dates)
+    north, south, _ = cal.hemisphere_season_tables(dates)
+    P, D, Y, n_doy = PERC.size, len(DEFS), north.shape[0], 365
+    lat = np.repeat(np.linspace(-90.0, 90.0, 192), 288).astype(np.float32)       # row-major (lat, lon)
+    lat_dev = torch.from_numpy(lat).to(dev)
+    idx = np.unique(np.linspace(0, n - 1, 64).astype(np.int64))
+    it = torch.from_numpy(idx).to(dev)
+
+    # ---- thresholds of the whole grid
+    xb = torch.empty(n * M * T, dtype=torch.float32, device=dev)                  # [cell][M * T]
+    _lib.check(lib.hdp_generate_series_dev(xb.data_ptr(), n, M * T, 0, lat_dev.data_ptr(), 0, 0.7, 0.0, stream))
+    tplan = core.ThresholdPlan(ti, cols, PERC, M * T)
+    thr = torch.empty((n, P, n_doy), dtype=torch.float64, device=dev)
+    tplan.run(xb.data_ptr(), n, thr.data_ptr(), stream)
+    torch.cuda.synchronize(dev)
+    assert not bool(torch.isnan(thr).any())
+    assert bool((thr[:, 1:, :] >= thr[:, :-1, :]).all())                          # monotone in q, every cell and day
+    xb2 = xb.view(n, M * T)
+    assert bool((thr.amax(dim=(1, 2)) <= xb2.amax(dim=1).double()).all())
+    assert bool((thr.amin(dim=(1, 2)) >= xb2.amin(dim=1).double()).all())
+    xs_b = xb2[it].cpu().numpy()
+    del xb2, xb
+    torch.cuda.empty_cache()
+
+    # ---- metrics of every member series against its cell's thresholds
+    lat_m = torch.from_numpy(np.tile(lat, M)).to(dev)
+    south_dev = torch.from_numpy(np.tile((lat < 0).astype(np.uint8), M)).to(dev)
+    xm = torch.empty(M * n * T, dtype=torch.float32, device=dev)                  # [member][cell][T]
+    _lib.check(lib.hdp_generate_series_dev(xm.data_ptr(), M * n, T, 0, lat_m.data_ptr(), 1, 0.7, 1.0 / 36500.0, stream))
+    mplan = core.MetricsPlan(dm, n_doy, DEFS, north, south, P)
+    out = torch.empty((4, P, D, Y, M * n), dtype=torch.int16, device=dev)
+    mplan.run(xm.data_ptr(), thr.data_ptr(), n, south_dev.data_ptr(), M * n, out.data_ptr(), stream)
+    torch.cuda.synchronize(dev)
+    total = 0
+    for p in range(P):                                                            # slabs of one percentile: 1.3 GB per metric
+        hwf, hwn, hwd, hwa = (out[i, p] for i in range(4))
+        assert bool((hwf >= 0).all()) and bool((hwd <= hwf).all()) and bool((hwn <= hwf).all())
+        assert bool((hwa == torch.where(hwn > 0, torch.div(hwf, hwn.clamp(min=1), rounding_mode="floor"),
+                                        torch.zeros_like(hwf))).all())
+        if p:   # a higher percentile never has more heatwave days under a definition without breaks (b == 0)
+            assert bool((hwf[::3] <= out[0, p - 1, ::3]).all())
+        total += int(hwf.sum(dtype=torch.int64))
+    assert total > 0
+
+    # ---- C oracle on 64 cells (all their members)
+    xs_m = xm.view(M, n, T)[:, it].cpu().numpy().reshape(M * idx.size, T)
+    th_g = thr[it].cpu().numpy().transpose(0, 2, 1)                               # [cells, n_doy, P]
+    rows = [0, 1, 100, 182, 357, 358, 364]                                        # the oracle sorts 15 000 samples per row
+    win = cal.expand_window_table(ti, cols)[rows]
+    assert np.array_equal(th_g[:, rows], c_oracle.thresholds(xs_b, win, PERC), equal_nan=True)
+    og = out.view(4, P, D, Y, M, n)[..., it].cpu().numpy()                        # [4, P, D, Y, M, 64]
+    met_g = np.transpose(og, (1, 2, 4, 5, 0, 3)).reshape(P, D, M * idx.size, 4, Y).astype(np.int64)
+    hemi = np.tile((lat[idx] < 0).astype(np.uint8), M)
+    assert np.array_equal(met_g, c_oracle.metrics(xs_m, np.concatenate([th_g] * M), dm, DEFS, north, south, hemi))
