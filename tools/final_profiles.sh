@@ -18,3 +18,5 @@ done > $O/bench_c3_qsets.txt 2>&1; cat $O/bench_c3_qsets.txt
 timeout -k 10 200 python bench.py --gpus 2 --backend gloo --share-device --cells 131072 --steps 2 --warmup 1 > $O/rehearsal.json 2> $O/rehearsal.err; echo "rehearsal rc=$?"
 tools/prof.sh ${TAG}_c3_65536 --cells 65536 --steps 2 --warmup 1 --no-tm > $O/prof.log 2>&1; echo "prof rc=$?"
 python3 tools/prof_summary.py gpurun_out/prof_${TAG}_c3_65536 > $O/c3_65536cells_rocprofv3_summary.txt
+tools/prof.sh ${TAG}_c5 --config c5 --steps 1 --warmup 1 --no-tm > $O/prof_c5.log 2>&1; echo "prof c5 rc=$?"
+python3 tools/prof_summary.py gpurun_out/prof_${TAG}_c5 > $O/c5_rocprofv3_summary.txt
