@@ -936,16 +936,23 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
                                                 const float *tail_cur, const uint32_t *flags, const uint16_t *cl, int r,
                                                 double *orow, const TgtLanes &tl_top, const TgtLanes &tl_bot,
                                                 int prio_phase = -1) {
+  // NaN / infinity census of the window: the columns' words are OR-ed first and summed only when one of them is set
+  // (almost never: 15 reads and ORs instead of 15 reads and five operations each, per row and item)
   RowFlags rf{0, 0};
-  uint32_t nan_or = 0;
+  uint32_t fw[4 * NG], nan_or = 0;
 #pragma unroll
   for (int j = 0; j < 4 * NG; ++j) {
-    const uint32_t f = (j < pd.W) ? flags[cl[j]] : 0u;
-    nan_or |= f;
-    rf.n_pos += (f >> 15) & 0x7fff;
-    rf.n_neg += f & 0x7fff;
+    fw[j] = (j < pd.W) ? flags[cl[j]] : 0u;
+    nan_or |= fw[j];
   }
-  if (nan_or >> 31) rf.n_pos = -1;
+  if (__ballot(nan_or != 0) != 0) {  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 4 * NG; ++j) {
+      rf.n_pos += (fw[j] >> 15) & 0x7fff;
+      rf.n_neg += fw[j] & 0x7fff;
+    }
+    if (nan_or >> 31) rf.n_pos = -1;
+  }
   merge_row_lean<true, NG, TIER, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_top, prio_phase);
   merge_row_lean<false, NG, false, ROWS>(pd, image, strips, tail_cur, cl, r, rf, orow, tl_bot, prio_phase);
   if (prio_phase >= 0) __builtin_amdgcn_s_setprio(3);
@@ -1730,18 +1737,18 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
               const float *tbase = tail_wg + size_t(s & 1) * tail_half;  // wave-uniform
               uint32_t toff = uint32_t(lc) * 4u;                          // one running byte offset (see the loads)
               const uint32_t trow = uint32_t(pd.tail_pitch) * 4u;
+              // the tail's global stores go out FIRST: their latency then runs under the LDS writes below instead of
+              // after them (both sit between the item's two barriers, where the merging waves wait)
 #pragma unroll
-              for (int i = 0; i < N; ++i) {
-                if (i < kTierK) {
-                  col[i] = __int_as_float(v[k][i]);
-                } else {
-                  // slots past S (padding) all land on the spare row behind the last sample's
-                  const uint32_t o = (i < lane_first_pad_slot(N)) ? toff : uint32_t(lc) * 4u + uint32_t(min(i, S_rt) - kTierK) * trow;
-                  asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(v[k][i]), "s"(tbase) : "memory");
-                  toff += trow;
-                  asm volatile("" : "+v"(toff));
-                }
+              for (int i = kTierK; i < N; ++i) {
+                // slots past S (padding) all land on the spare row behind the last sample's
+                const uint32_t o = (i < lane_first_pad_slot(N)) ? toff : uint32_t(lc) * 4u + uint32_t(min(i, S_rt) - kTierK) * trow;
+                asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(v[k][i]), "s"(tbase) : "memory");
+                toff += trow;
+                asm volatile("" : "+v"(toff));
               }
+#pragma unroll
+              for (int i = 0; i < kTierK && i < N; ++i) col[i] = __int_as_float(v[k][i]);
               col[kTierK] = __uint_as_float(0x7ff00000u | uint32_t(lc));
               col[kTierK + 1] = __uint_as_float(kRawMin);  // what the heads of window slots past W read
               // the tail stores are asm (the compiler does not count them) and a merging wave may read them back from L2:
