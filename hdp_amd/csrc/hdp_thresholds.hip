@@ -668,8 +668,11 @@ constexpr int kWholeThreads = 768;                   // 6 merging + 6 producing 
 constexpr int kTierK = HDP_TIERK;                           // tiered image: samples of a column kept in LDS (plans with S > 64)
 constexpr uint32_t kRawMax = 0x7fe00000u;            // above +inf (0x7f800000), finite as the high word of a double
 constexpr uint32_t kRawMin = 0xffe00000u;            // below -inf (0xff800000)
+constexpr int kHG = 3;        // heads per group of the lean merge (round 4: groups of three, NG = 3 or 5 groups; rounds 2-3: four of four)
+constexpr int kListPitch = 16;  // uint16 entries per row of the window column lists in LDS (3 * NG <= 15 used)
+constexpr uint32_t kPayGroupShift = 18;  // payload: LDS byte address in bits 0..17, group in 18..20, tail position 21..27, tail flag 30
 template <int NG, int ROWS>
-constexpr size_t lean_strip_bytes() { return size_t(NG) * ROWS * 24; }
+constexpr size_t lean_strip_bytes() { return size_t(NG) * ROWS * 16; }
 
 // The emission tables of one merge direction held ACROSS THE LANES of a few registers: lane k has target k's rank, its
 // (quantile | kind << 16) word and that quantile's parameters.  An emission then reads them with v_readlane (a
@@ -749,7 +752,7 @@ template <bool TOP, int NG, bool TIER, int ROWS>
 __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned char *image, unsigned char *strips,
                                                const float *tail_cur, const uint16_t *cl, int r, const RowFlags &rf,
                                                double *orow, const TgtLanes &tl, int prio_phase = -1) {
-  static_assert(NG >= 1 && NG <= 4, "group id is two payload bits");
+  static_assert(NG >= 1 && NG <= 7, "group id is three payload bits");
   const int steps = TOP ? pd.steps_top : pd.steps_bot;
   const int nt = TOP ? pd.nt_top : pd.nt_bot;
   const int2 *tgt = TOP ? pd.tgt_top : pd.tgt_bot;
@@ -757,49 +760,41 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
   auto better = [](double a, double b) { return TOP ? pk_max(a, b) : pk_min(a, b); };
   auto worse = [](double a, double b) { return TOP ? pk_min(a, b) : pk_max(a, b); };
   auto head = [](uint32_t bits, uint32_t pay) { return __hiloint2double(int(bits), int(pay)); };
-  // strips: A[g][row] = (2nd, 3rd) 16 bytes, B[g][row] = 4th 8 bytes
+  // strips: [g][row] = (2nd, 3rd head of the group) 16 bytes -- one ds_read_b128 and one ds_write_b128 per step
   unsigned char *const sA = strips + size_t(r) * 16;
-  unsigned char *const sB = strips + size_t(NG) * ROWS * 16 + size_t(r) * 8;
   double m[NG];
   {
     // column heads: first (TOP) or last (bottom) sample of each window column.  The row's column list is padded to
-    // 4 * NG entries with the pseudo column (all sentinels), so this is branch-free: two 16-byte reads of the list,
+    // 3 * NG entries with the pseudo column (all sentinels), so this is branch-free: two 16-byte reads of the list,
     // every head read in flight at once.
-    uint32_t pos[4 * NG];
+    uint32_t pos[kHG * NG];
     // absolute LDS byte address of the image (the low 32 bits of a generic pointer into LDS): heads carry absolute
     // addresses, so a step's next-key read needs no base add
     const uint32_t img0 = uint32_t(reinterpret_cast<uintptr_t>(image));
     {
       const uint4 *cl4 = reinterpret_cast<const uint4 *>(cl);
 #pragma unroll
-      for (int v4 = 0; v4 < NG / 2 + (NG & 1); ++v4) {
-        uint32_t wv[4];
-        if (NG == 1) {
-          const uint2 h = *reinterpret_cast<const uint2 *>(cl);
-          wv[0] = h.x; wv[1] = h.y; wv[2] = wv[3] = 0;
-        } else {
-          const uint4 q4 = cl4[v4];
-          wv[0] = q4.x; wv[1] = q4.y; wv[2] = q4.z; wv[3] = q4.w;
-        }
+      for (int v4 = 0; v4 < 2; ++v4) {
+        const uint4 q4 = cl4[v4];
+        const uint32_t wv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int j0 = v4 * 8 + 2 * u;
-          if (j0 < 4 * NG) pos[j0] = img0 + uint32_t(int(wv[u] & 0xffffu) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
-          if (j0 + 1 < 4 * NG) pos[j0 + 1] = img0 + uint32_t(int(wv[u] >> 16) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
+          if (j0 < kHG * NG) pos[j0] = img0 + uint32_t(int(wv[u] & 0xffffu) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
+          if (j0 + 1 < kHG * NG) pos[j0 + 1] = img0 + uint32_t(int(wv[u] >> 16) * pd.img_pitch + (TOP ? 1 : pd.S)) * 4u;
         }
       }
     }
-    uint32_t kb[4 * NG];
+    uint32_t kb[kHG * NG];
 #pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) kb[j] = lds_u32(pos[j]);
+    for (int j = 0; j < kHG * NG; ++j) kb[j] = lds_u32(pos[j]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      double hd[4];
+      double hd[kHG];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) hd[i] = head(kb[4 * g + i], pos[4 * g + i] | uint32_t(g));
-      sort_best_first<TOP, 4>(hd);
+      for (int i = 0; i < kHG; ++i) hd[i] = head(kb[kHG * g + i], pos[kHG * g + i] | (uint32_t(g) << kPayGroupShift));
+      sort_best_first<TOP, kHG>(hd);
       *reinterpret_cast<double2 *>(sA + g * (ROWS * 16)) = make_double2(hd[1], hd[2]);
-      *reinterpret_cast<double *>(sB + g * (ROWS * 8)) = hd[3];
       m[g] = hd[0];
     }
     sort_best_first<TOP, NG>(m);
@@ -810,24 +805,20 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
 
   uint32_t nk;      // next key (float bits) of the popped column
   double2 h12;      // popped group's 2nd and 3rd head
-  double h3;        // ... and 4th
   uint32_t lo_cur;  // payload of the popped head
-  uint32_t aA, aB;  // absolute LDS addresses of the popped group's strips: computed for the reads, reused by the write-back
-  const uint32_t sA0 = uint32_t(reinterpret_cast<uintptr_t>(sA)), sB0 = uint32_t(reinterpret_cast<uintptr_t>(sB));
+  uint32_t aA;      // absolute LDS address of the popped group's strip: computed for the read, reused by the write-back
+  const uint32_t sA0 = uint32_t(reinterpret_cast<uintptr_t>(sA));
   typedef double v2f64 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) v2f64 *lds_d2;
-  typedef __attribute__((address_space(3))) double *lds_d1;
   auto issue = [&](double top) {
     lo_cur = uint32_t(__double2loint(top));
-    const uint32_t g = lo_cur & 3u;
-    aB = __umul24(g, uint32_t(ROWS * 8)) + sB0;
+    const uint32_t g = __builtin_amdgcn_ubfe(lo_cur, kPayGroupShift, 3);
     aA = __umul24(g, uint32_t(ROWS * 16)) + sA0;
-    nk = lds_u32((lo_cur & 0x3fffcu) + (TOP ? 4u : uint32_t(-4)));  // payloads hold absolute LDS addresses
+    nk = lds_u32((lo_cur & 0x3ffffu) + (TOP ? 4u : uint32_t(-4)));  // payloads hold absolute LDS addresses
     {
       const v2f64 t = *reinterpret_cast<lds_d2>(uintptr_t(aA));
       h12 = make_double2(t.x, t.y);
     }
-    h3 = *reinterpret_cast<lds_d1>(uintptr_t(aB));
   };
   issue(m[0]);
   // One step (round 4: written back BEFORE the next step's reads are issued).  Rounds 2-3 issued the next step's reads
@@ -845,12 +836,12 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
       // as a signed int it is above every sample and both sentinels).  Reading it means the column's next sample
       // lives in the workgroup's global tail: fetch it there.  A head that came from the tail keeps pointing at
       // slot tier_k (so its "next key" read finds the marker, and with it the column, again) and carries its own
-      // position in payload bits 18..28 under flag bit 30.  Rare by construction (a column must supply more than
+      // position in payload bits 21..27 under flag bit 30.  Rare by construction (a column must supply more than
       // tier_k of a window's top ranks), so the wave takes this branch only when some lane needs it.
       const bool mk = int(nk) >= int(0x7ff00000u);
       if (__ballot(mk) != 0) {
         const uint32_t c = nk & 0xfffffu;
-        const uint32_t p1n = (lo_cur & 0x40000000u) ? ((lo_cur >> 18) & 0x7ffu) + 1u : uint32_t(pd.tier_k) + 1u;
+        const uint32_t p1n = (lo_cur & 0x40000000u) ? ((lo_cur >> 21) & 0x7fu) + 1u : uint32_t(pd.tier_k) + 1u;
         uint32_t v = kRawMin;  // past the column's last sample: the losing sentinel
         if (mk && p1n <= uint32_t(pd.S)) {
           const uint32_t off = ((p1n - uint32_t(pd.tier_k) - 1u) * uint32_t(pd.tail_pitch) + c) * 4u;
@@ -859,7 +850,7 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
         }
         if (mk) {
           nk = v;
-          pay = 0x40000000u | (p1n << 18) | (lo_cur & 0x3ffffu);
+          pay = 0x40000000u | (p1n << 21) | (lo_cur & 0x1fffffu);   // address and group kept
         }
       }
     }
@@ -867,11 +858,8 @@ __device__ __forceinline__ void merge_row_lean(const ThrDev &pd, const unsigned 
     const double t0 = better(fresh, h12.x);  // the group's new top
     const double w1 = worse(fresh, h12.x);
     const double b1 = better(w1, h12.y);
-    const double w2 = worse(w1, h12.y);
-    const double b2 = better(w2, h3);
-    const double b3 = worse(w2, h3);
+    const double b2 = worse(w1, h12.y);
     *reinterpret_cast<lds_d2>(uintptr_t(aA)) = v2f64{b1, b2};
-    *reinterpret_cast<lds_d1>(uintptr_t(aB)) = b3;
     double m0n = t0;
     if constexpr (NG >= 2) m0n = better(t0, m[1]);
     __builtin_amdgcn_sched_barrier(0);
@@ -939,15 +927,15 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
   // NaN / infinity census of the window: the columns' words are OR-ed first and summed only when one of them is set
   // (almost never: 15 reads and ORs instead of 15 reads and five operations each, per row and item)
   RowFlags rf{0, 0};
-  uint32_t fw[4 * NG], nan_or = 0;
+  uint32_t fw[kHG * NG], nan_or = 0;
 #pragma unroll
-  for (int j = 0; j < 4 * NG; ++j) {
+  for (int j = 0; j < kHG * NG; ++j) {
     fw[j] = (j < pd.W) ? flags[cl[j]] : 0u;
     nan_or |= fw[j];
   }
   if (__ballot(nan_or != 0) != 0) {  // wave-uniform
 #pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) {
+    for (int j = 0; j < kHG * NG; ++j) {
       rf.n_pos += (fw[j] >> 15) & 0x7fff;
       rf.n_neg += fw[j] & 0x7fff;
     }
@@ -975,7 +963,7 @@ template <bool TOP, int NG, int ROWS>
 __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg, const int2 *tgt, const unsigned char *image,
                                               unsigned char *strips, const uint16_t *cl, int r, const RowFlags &rf,
                                               double *orow, bool store, const TgtLanes &tl) {
-  static_assert(NG >= 1 && NG <= 4, "group id is two payload bits");
+  static_assert(NG >= 1 && NG <= 7, "group id is three payload bits");
   const int steps = sg.steps, nt = sg.nt;
   if (steps == 0) return;
   auto better = [](double a, double b) { return TOP ? pk_max(a, b) : pk_min(a, b); };
@@ -988,38 +976,32 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
   };
   const int rp = pd.RP;  // strip pitch of a segmented plan: the block's rows rounded up to 64 (not the ROWS of the classic form)
   unsigned char *const sA = strips + size_t(r) * 16;
-  unsigned char *const sB = strips + size_t(NG) * rp * 16 + size_t(r) * 8;
   const uint32_t img0 = uint32_t(reinterpret_cast<uintptr_t>(image));
   const int S = pd.S, W = pd.W;
-  uint32_t cbase[4 * NG];  // LDS byte address of slot 0 of every window column (padding entries: the pseudo column)
+  constexpr int NC = kHG * NG;  // window slots (padding entries: the pseudo column)
+  uint32_t cbase[NC];           // LDS byte address of slot 0 of every window column
   {
     const uint4 *cl4 = reinterpret_cast<const uint4 *>(cl);
 #pragma unroll
-    for (int v4 = 0; v4 < NG / 2 + (NG & 1); ++v4) {
-      uint32_t wv[4];
-      if (NG == 1) {
-        const uint2 h = *reinterpret_cast<const uint2 *>(cl);
-        wv[0] = h.x; wv[1] = h.y; wv[2] = wv[3] = 0;
-      } else {
-        const uint4 q4 = cl4[v4];
-        wv[0] = q4.x; wv[1] = q4.y; wv[2] = q4.z; wv[3] = q4.w;
-      }
+    for (int v4 = 0; v4 < 2; ++v4) {
+      const uint4 q4 = cl4[v4];
+      const uint32_t wv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j0 = v4 * 8 + 2 * u;
-        if (j0 < 4 * NG) cbase[j0] = img0 + uint32_t(int(wv[u] & 0xffffu) * pd.img_pitch) * 4u;
-        if (j0 + 1 < 4 * NG) cbase[j0 + 1] = img0 + uint32_t(int(wv[u] >> 16) * pd.img_pitch) * 4u;
+        if (j0 < NC) cbase[j0] = img0 + uint32_t(int(wv[u] & 0xffffu) * pd.img_pitch) * 4u;
+        if (j0 + 1 < NC) cbase[j0 + 1] = img0 + uint32_t(int(wv[u] >> 16) * pd.img_pitch) * 4u;
       }
     }
   }
   // ---- entry: slot of every column's first head, and the rank C the lane starts from
-  uint32_t start[4 * NG];
+  uint32_t start[NC];
   int C = 0;
   {
     int p = sg.pivot_pos;  // wave-uniform
     while (true) {
 #pragma unroll
-      for (int j = 0; j < 4 * NG; ++j) start[j] = uint32_t(TOP ? 1 : S);
+      for (int j = 0; j < NC; ++j) start[j] = uint32_t(TOP ? 1 : S);
       C = 0;
       if (p <= 0) break;
       // pivot: the MEAN of the window columns' p-th samples counted from the walk's own end (any value will do; one
@@ -1030,7 +1012,7 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
       {
         float acc = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4 * NG; ++j)
+        for (int j = 0; j < NC; ++j)
           if (j < W) acc += __uint_as_float(lds_u32(cbase[j] + uint32_t(TOP ? p : S + 1 - p) * 4u));
         acc *= 1.0f / float(W);
         v = __float_as_uint(acc);
@@ -1039,23 +1021,23 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
       // pos_j = samples of column j ranked before v, by descent in strides from the column's own end.  The columns are
       // sorted descending: slot 1 the largest, slot S the smallest, sentinels at 0 and S + 1 (never "before" anything).
       //   TOP: pos_j counts from slot 1 down;  bottom: pos_j counts from slot S up (slot S + 1 - idx).
-      uint32_t pos[4 * NG];
+      uint32_t pos[NC];
 #pragma unroll
-      for (int j = 0; j < 4 * NG; ++j) pos[j] = 0;
+      for (int j = 0; j < NC; ++j) pos[j] = 0;
       for (int stride = 64; stride >= 1; stride >>= 1) {  // S <= 100 in this kernel: 7 strides reach 127
-        uint32_t idx[4 * NG], k[4 * NG];
+        uint32_t idx[NC], k[NC];
 #pragma unroll
-        for (int j = 0; j < 4 * NG; ++j) {
+        for (int j = 0; j < NC; ++j) {
           idx[j] = min(pos[j] + uint32_t(stride), uint32_t(S + 1));
           k[j] = lds_u32(cbase[j] + (TOP ? idx[j] : uint32_t(S + 1) - idx[j]) * 4u);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4 * NG; ++j) pos[j] = before(k[j], v) ? idx[j] : pos[j];
+        for (int j = 0; j < NC; ++j) pos[j] = before(k[j], v) ? idx[j] : pos[j];
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int j = 0; j < 4 * NG; ++j) {
+      for (int j = 0; j < NC; ++j) {
         if (j < W) {
           C += int(pos[j]);
           start[j] = TOP ? pos[j] + 1u : uint32_t(S) - pos[j];
@@ -1067,19 +1049,18 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
   }
   double m[NG];
   {
-    uint32_t pos[4 * NG], kb[4 * NG];
+    uint32_t pos[NC], kb[NC];
 #pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) pos[j] = cbase[j] + start[j] * 4u;
+    for (int j = 0; j < NC; ++j) pos[j] = cbase[j] + start[j] * 4u;
 #pragma unroll
-    for (int j = 0; j < 4 * NG; ++j) kb[j] = lds_u32(pos[j]);
+    for (int j = 0; j < NC; ++j) kb[j] = lds_u32(pos[j]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      double hd[4];
+      double hd[kHG];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) hd[i] = head(kb[4 * g + i], pos[4 * g + i] | uint32_t(g));
-      sort_best_first<TOP, 4>(hd);
+      for (int i = 0; i < kHG; ++i) hd[i] = head(kb[kHG * g + i], pos[kHG * g + i] | (uint32_t(g) << kPayGroupShift));
+      sort_best_first<TOP, kHG>(hd);
       *reinterpret_cast<double2 *>(sA + g * (rp * 16)) = make_double2(hd[1], hd[2]);
-      *reinterpret_cast<double *>(sB + g * (rp * 8)) = hd[3];
       m[g] = hd[0];
     }
     sort_best_first<TOP, NG>(m);
@@ -1103,22 +1084,18 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
   int k = 0;
   int next_rank = nt > 0 ? (tl.ok ? __builtin_amdgcn_readlane(tl.rank, 0) : ldk(&tgt[0]).x) : -1;
   double prev = head(TOP ? kRawMin : kRawMax, 0);
-  uint32_t nk, lo_cur, aA, aB;
+  uint32_t nk, lo_cur, aA;
   double2 h12;
-  double h3;
-  const uint32_t sA0 = uint32_t(reinterpret_cast<uintptr_t>(sA)), sB0 = uint32_t(reinterpret_cast<uintptr_t>(sB));
+  const uint32_t sA0 = uint32_t(reinterpret_cast<uintptr_t>(sA));
   typedef double v2f64 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) v2f64 *lds_d2;
-  typedef __attribute__((address_space(3))) double *lds_d1;
   auto issue = [&](double top) {
     lo_cur = uint32_t(__double2loint(top));
-    const uint32_t g = lo_cur & 3u;
-    aB = __umul24(g, uint32_t(rp * 8)) + sB0;
+    const uint32_t g = __builtin_amdgcn_ubfe(lo_cur, kPayGroupShift, 3);
     aA = __umul24(g, uint32_t(rp * 16)) + sA0;
-    nk = lds_u32((lo_cur & 0x3fffcu) + (TOP ? 4u : uint32_t(-4)));
+    nk = lds_u32((lo_cur & 0x3ffffu) + (TOP ? 4u : uint32_t(-4)));
     const v2f64 t = *reinterpret_cast<lds_d2>(uintptr_t(aA));
     h12 = make_double2(t.x, t.y);
-    h3 = *reinterpret_cast<lds_d1>(uintptr_t(aB));
   };
   auto do_step = [&]() {  // as merge_row_lean's (untiered)
     const uint32_t pay = lo_cur + (TOP ? 4u : uint32_t(-4));
@@ -1126,11 +1103,8 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
     const double t0 = better(fresh, h12.x);
     const double w1 = worse(fresh, h12.x);
     const double b1 = better(w1, h12.y);
-    const double w2 = worse(w1, h12.y);
-    const double b2 = better(w2, h3);
-    const double b3 = worse(w2, h3);
+    const double b2 = worse(w1, h12.y);
     *reinterpret_cast<lds_d2>(uintptr_t(aA)) = v2f64{b1, b2};
-    *reinterpret_cast<lds_d1>(uintptr_t(aB)) = b3;
     double m0n = t0;
     if constexpr (NG >= 2) m0n = better(t0, m[1]);
     __builtin_amdgcn_sched_barrier(0);
@@ -1570,9 +1544,9 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   unsigned char *strips = smem + off;  // merge heads: 2nd..4th of every (group, row), see merge_row_lean
   constexpr bool kCanSeg = ROWS == kLeanRows;  // the whole-cell form never cuts its walks into runs: nothing of this in its code
   const int n_segs = kCanSeg ? pd.n_segs : 0;
-  const size_t seg_strip_bytes = size_t(NG) * size_t(pd.RP) * 24;  // segmented: one set of strips per run, pitch = rows rounded to 64
+  const size_t seg_strip_bytes = size_t(NG) * size_t(pd.RP) * 16;  // segmented: one set of strips per run, pitch = rows rounded to 64
   off += n_segs > 0 ? seg_strip_bytes * size_t(n_segs) : lean_strip_bytes<NG, ROWS>();
-  uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][4 * NG] local columns of this block's windows (slots past W: the pseudo column)
+  uint16_t *cl_lds = reinterpret_cast<uint16_t *>(smem + off);  // [rows][kListPitch] local columns of this block's windows (slots past W: the pseudo column)
 
   const int nb = pd.n_blocks;
   const int blk = int(blockIdx.x) % nb;
@@ -1588,8 +1562,8 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   // this workgroup's global tail (tiered image), double-buffered by item parity like the census words
   const size_t tail_half = size_t(max(pd.S - pd.tier_k, 0) + 1) * pd.tail_pitch;
   float *const tail_wg = pd.tail + size_t(blockIdx.x) * 2 * tail_half;
-  for (int i = tid; i < nrows * 4 * NG; i += int(blockDim.x)) {
-    const int r = i / (4 * NG), j = i % (4 * NG);
+  for (int i = tid; i < nrows * kListPitch; i += int(blockDim.x)) {
+    const int r = i / kListPitch, j = i % kListPitch;
     cl_lds[i] = (j < pd.W) ? pd.cols_local[size_t(row0 + r) * pd.W + j] : uint16_t(pd.ncols_max);
   }
   // the pseudo column: every slot a head could start from reads as a loser (top walks start at slot 1, bottom walks at
@@ -1800,12 +1774,12 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
           if (s >= 1 && mrow < nm_rows * 64) {
             const int64_t cell = first_cell + (s - 1) * wg_per_blk;
             const int rr = min(mrow, nrows - 1);
-            const uint16_t *cl = cl_lds + rr * (4 * NG);
+            const uint16_t *cl = cl_lds + rr * kListPitch;
             double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row0 + rr;  // [cell][P][n_doy]
             RowFlags rf{0, 0};
             uint32_t nan_or = 0;
 #pragma unroll
-            for (int j = 0; j < 4 * NG; ++j) {
+            for (int j = 0; j < kHG * NG; ++j) {
               const uint32_t f = (j < pd.W) ? flags_m[cl[j]] : 0u;
               nan_or |= f;
               rf.n_pos += (f >> 15) & 0x7fff;
@@ -1822,7 +1796,7 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
       } else if (s >= 1 && mrow < nrows) {
         const int64_t cell = first_cell + (s - 1) * wg_per_blk;
         const int row = row0 + mrow;
-        const uint16_t *cl = cl_lds + mrow * (4 * NG);
+        const uint16_t *cl = cl_lds + mrow * kListPitch;
         double *orow = out + cell * pd.n_doy * int64_t(pd.P) + row;  // [cell][P][n_doy]
 #if !(defined(HDP_LANE_ABL) && (HDP_LANE_ABL & 1))
         // ranks >= 4 are the second merging wave of their SIMD (roles above: one merging wave per SIMD first)
@@ -2008,34 +1982,32 @@ static int launch_thr_lane(const ThrDev &pd, size_t lds, const float *x, int64_t
   const int n_tasks = (pd.ncols_max + 63) / 64;
   const bool whole = pd.n_blocks == 1 && pd.RP > kLeanRows;  // the plan put every row of a cell into one workgroup
   const int threads = std::min<int>(whole ? kWholeThreads : kThrThreads, 64 * (pd.n_merge + (n_tasks + tpw - 1) / tpw));
-  switch (pd.Wp >> 2) {
-    case 1:  // windows of up to four columns run the two-group kernels (their lists are padded with the pseudo column)
-    case 2:
-      // whole-cell form: tiered image for columns of more than 64 samples (the plan makes every such whole-cell plan
-      // tiered), whole columns in LDS up to 64
+  // head groups of three: windows of up to 9 columns run with three groups, up to 15 with five (their lists are padded
+  // with the pseudo column).  Whole-cell form: tiered image for columns of more than 64 samples (the plan makes every such
+  // whole-cell plan tiered), whole columns in LDS up to 64.
+  switch (pd.W <= 9 ? 3 : (pd.W <= 15 ? 5 : 0)) {
+    case 3:
       if constexpr (N > 64) {
         if (whole) {
           HDP_REQUIRE(pd.tier_k < pd.S, HDP_EUNSUP, "whole-cell plan without a tiered image for S = %d", pd.S);
-          return launch_thr_persistent(thresholds_lane_kernel<N, 2, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+          return launch_thr_persistent(thresholds_lane_kernel<N, 3, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
         }
       } else {
         if (whole)
-          return launch_thr_persistent(thresholds_lane_kernel<N, 2, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
+          return launch_thr_persistent(thresholds_lane_kernel<N, 3, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
       }
-      return launch_thr_persistent(thresholds_lane_kernel<N, 2, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
-    case 4:
-      // whole-cell form: tiered image for columns of more than 64 samples (the plan makes every such whole-cell plan
-      // tiered), whole columns in LDS up to 64
+      return launch_thr_persistent(thresholds_lane_kernel<N, 3, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
+    case 5:
       if constexpr (N > 64) {
         if (whole) {
           HDP_REQUIRE(pd.tier_k < pd.S, HDP_EUNSUP, "whole-cell plan without a tiered image for S = %d", pd.S);
-          return launch_thr_persistent(thresholds_lane_kernel<N, 4, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
+          return launch_thr_persistent(thresholds_lane_kernel<N, 5, true, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, tail_buf);
         }
       } else {
         if (whole)
-          return launch_thr_persistent(thresholds_lane_kernel<N, 4, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
+          return launch_thr_persistent(thresholds_lane_kernel<N, 5, false, kWholeRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
       }
-      return launch_thr_persistent(thresholds_lane_kernel<N, 4, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
+      return launch_thr_persistent(thresholds_lane_kernel<N, 5, false, kLeanRows>, pd, lds, x, n_cells, out, grid_override, threads, stream, nullptr);
     default: return set_error(HDP_EUNSUP, "lane-per-column kernel: unsupported window width");
   }
 }
@@ -2077,7 +2049,7 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
     snprintf(buf, sizeof buf,
              "thresholds_lane_kernel<N=%d,NG=%d%s> (one lane per column: register merge-exchange sort; %d merging waves; "
              "%d rows x %d blocks, %zu B LDS%s)",
-             plan->lane_n, std::max(2, plan->Wp >> 2),
+             plan->lane_n, plan->W <= 9 ? 3 : 5,
              plan->lane_tier_k < plan->S ? ",tiered,whole-cell" : (plan->n_blocks == 1 && plan->RP > hdp::kLeanRows ? ",whole-cell" : (plan->lane_n_segs > 0 ? ",segmented" : "")), plan->lane_n_merge,
              plan->rows_per_block, plan->n_blocks, plan->lane_lds_bytes,
              plan->lane_tier_k < plan->S ? "; top 60 samples of a column in LDS, the rest in a global tail" : "");
@@ -2402,20 +2374,20 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   bool whole = false;
   size_t whole_lds = 0;
   {
-    const int ngw0 = std::max(2, pl->Wp >> 2);  // the lane kernel's head groups: instantiated for 2 and 4 (windows of <= 4 columns run as 2)
+    const int ngw0 = W <= 9 ? 3 : (W <= 15 ? 5 : 0);  // the lane kernel's head groups of three: instantiated for 3 and 5
     // tiered (more than 64 samples per column: top-side quantiles only, bottom walks would start in the global tail) or
     // with whole columns in LDS (up to 64 samples: any quantiles)
     const bool tiered = S > 64;
     // (a walk deeper than ~8 samples per column and tier slot would spend its steps fetching from the global tail)
-    const bool cand = S >= 3 && S <= 100 && (!tiered || (pl->steps_bot == 0 && pl->steps_top <= 8 * hdp::kTierK)) && (ngw0 == 2 || ngw0 == 4) &&
+    const bool cand = S >= 3 && S <= 100 && (!tiered || (pl->steps_bot == 0 && pl->steps_top <= 8 * hdp::kTierK)) && (ngw0 == 3 || ngw0 == 5) &&
                       pl->opt_lane != 0 && pl->opt_pipe != 0 && opt_rows <= 0 && hdp::env_option("HDP_THR_WHOLE", 1) != 0;
     if (cand && n_doy <= hdp::kWholeRows && n_doy > hdp::kLeanRows) {
       int ip = tiered ? hdp::kTierK + 3 : spad;
       if ((ip & 1) == 0) ++ip;
       size_t b = (size_t(n_doy + 1) * ip * 4 + 15) & ~size_t(15);
       b += 2 * ((size_t(n_doy) * 4 + 15) & ~size_t(15));
-      b += size_t(ngw0) * hdp::kWholeRows * 24;
-      b += (size_t(n_doy) * 4 * ngw0 * 2 + 15) & ~size_t(15);
+      b += size_t(ngw0) * hdp::kWholeRows * 16;
+      b += (size_t(n_doy) * hdp::kListPitch * 2 + 15) & ~size_t(15);
       const int n_slots = hdp::lane_slots_for(S);
       const int waves = int((n_doy + 63) / 64) + (int((n_doy + 63) / 64) + hdp::lane_tasks_per_wave_rt(n_slots) - 1) / hdp::lane_tasks_per_wave_rt(n_slots);
       if (b <= kMaxLds && waves * 64 <= hdp::kWholeThreads) {
@@ -2456,9 +2428,9 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
                      (long long)W, (long long)S);
   }
   // lane-per-column kernel: every producer wave sorts (and holds) up to lane_tasks_per_wave tasks of 64 columns
-  const int ngw = std::max(2, pl->Wp >> 2);  // head groups of four of the lane kernel: instantiated for 2 and 4
+  const int ngw = W <= 9 ? 3 : (W <= 15 ? 5 : 0);  // head groups of three of the lane kernel: instantiated for 3 and 5
   // (S >= 3: the pseudo column that pads the window lists must lose from slot 1 going down AND from slot S going up)
-  const int lane_n = ((ngw == 2 || ngw == 4) && S >= 3) ? hdp::lane_slots_for(S) : 0;
+  const int lane_n = ((ngw == 3 || ngw == 5) && S >= 3) ? hdp::lane_slots_for(S) : 0;
   auto lane_ok = [&](int r, int ncols_max) -> bool {
     if (!lane_n) return false;
     const int nm = (r + 63) / 64, np = hdp::kThrThreads / 64 - nm;
@@ -2495,8 +2467,8 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
     // kLeanRows), window column lists
     size_t b = (size_t(cm + 1) * ip * 4 + 15) & ~size_t(15);
     b += 2 * ((size_t(cm) * 4 + 15) & ~size_t(15));
-    b += size_t(ngw) * hdp::kLeanRows * 24;
-    b += (size_t(rows) * 4 * ngw * 2 + 15) & ~size_t(15);
+    b += size_t(ngw) * hdp::kLeanRows * 16;
+    b += (size_t(rows) * hdp::kListPitch * 2 + 15) & ~size_t(15);
     pl->lane_lds_bytes = whole ? whole_lds : b;
     if (!whole && (b > kMaxLds || rows > hdp::kLeanRows)) pl->lane = false;
     // Segmented form of the blocked kernel (round 4; the round-3 "dual" form was its two-run case without pivots): the
@@ -2572,8 +2544,8 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
           if (nm2 + (n_tasks + tpw - 1) / tpw > hdp::kThrThreads / 64) continue;
           size_t bd = (size_t(c2 + 1) * ip * 4 + 15) & ~size_t(15);
           bd += 2 * ((size_t(c2) * 4 + 15) & ~size_t(15));
-          bd += size_t(ns) * size_t(ngw) * size_t((rb + 63) & ~63) * 24;
-          bd += (size_t(rb) * 4 * ngw * 2 + 15) & ~size_t(15);
+          bd += size_t(ns) * size_t(ngw) * size_t((rb + 63) & ~63) * 16;
+          bd += (size_t(rb) * hdp::kListPitch * 2 + 15) & ~size_t(15);
           if (bd > (kMaxLds + 1024) / 2 - 512 && !(ns > 2 && bd <= kMaxLds)) continue;  // two workgroups per CU (one when many runs)
           rows = rb;
           cm = c2;
