@@ -120,6 +120,7 @@ struct hdp_threshold_plan {
     if (tm_stream) (void)hipStreamDestroy(tm_stream);
   }
   // lane-per-column kernel (S <= 100, W <= 16): one lane sorts one column in registers, no cross-lane stage
+  int32_t lane_stride = 0;       // lane kernel: bytes between consecutive samples of every column (0: irregular)
   int32_t lane_n_segs = 0;       // blocked lane kernel, segmented walks: runs of requested ranks, each on its own merging waves
   hdp::DevBuf lane_segs;         // ThrSeg [lane_n_segs]
   int32_t lane_n_merge = 0;      // merging waves of the lane kernel (runs x n_merge in the segmented form)

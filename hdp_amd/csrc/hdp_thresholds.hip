@@ -64,6 +64,7 @@ struct ThrDev {
   const struct ThrSeg *segs;
   float *tail;
   int n_merge;                                 // merging waves
+  int lane_stride;                             // lane kernel: bytes between consecutive samples of every column (0: irregular, use the table)
   int select;                                  // one-workgroup-per-cell kernel: rank selection instead of the merge
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
   int steps_top, steps_bot, nt_top, nt_bot, n;
@@ -1632,17 +1633,34 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
             // byte offsets first (coalesced, L2-resident table), then the samples: lanes = adjacent columns =
             // adjacent time steps, so a load instruction fetches 256 contiguous bytes on a regular calendar.
             // The table has N rows: rows past S repeat row S - 1 and are overwritten with the sentinel key below.
-            uint32_t toff = lane_b;
+            if (pd.lane_stride != 0) {  // wave-uniform
+              // Regular columns (every sample of a column is `lane_stride` bytes behind the one before: any calendar
+              // without ragged or padded columns -- the plan checks): ONE offset per lane from the table, the sample
+              // index goes into the load's scalar base.  100 table loads, their wait and 100 vector adds less per task.
+              int off0 = ld_saddr(tl, lane_b);
+              wait_vm0();
+              landed(off0);
+              const char *base = xc;
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-              v[k][i] = ld_saddr(tl, toff);
-              toff += pitch4;
-              asm volatile("" : "+v"(toff));  // one running offset: the N row offsets are loop invariants the compiler
-                                               // would otherwise keep in N registers across the whole item loop
+              for (int i = 0; i < N; ++i) {
+                v[k][i] = ld_saddr(base, uint32_t(off0));
+                // rows past S repeat sample S - 1 (they are overwritten with the sentinel key below)
+                if (i < lane_first_pad_slot(N) - 1 || i + 1 < S_rt) base += pd.lane_stride;
+                asm volatile("" : "+s"(base));  // a running scalar base, not N loop-invariant pairs
+              }
+            } else {
+              uint32_t toff = lane_b;
+#pragma unroll
+              for (int i = 0; i < N; ++i) {
+                v[k][i] = ld_saddr(tl, toff);
+                toff += pitch4;
+                asm volatile("" : "+v"(toff));  // one running offset: the N row offsets are loop invariants the compiler
+                                                 // would otherwise keep in N registers across the whole item loop
+              }
+              wait_vm0();
+#pragma unroll
+              for (int i = 0; i < N; ++i) ld_saddr_inplace(xc, v[k][i]);
             }
-            wait_vm0();
-#pragma unroll
-            for (int i = 0; i < N; ++i) ld_saddr_inplace(xc, v[k][i]);
             wait_vm0();
 #pragma unroll
             for (int i = 0; i < N; ++i) landed(v[k][i]);
@@ -2099,6 +2117,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.n_merge = plan->n_merge;
   pd.n_segs = 0;
   pd.segs = nullptr;
+  pd.lane_stride = 0;
   pd.tixl = plan->tixl.as<int32_t>();
   pd.blk_tixl_off = plan->blk_tixl_off.as<int32_t>();
   pd.tier_k = plan->lane_tier_k;
@@ -2127,6 +2146,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   if (var.lane) {
     pd.n_merge = plan->lane_n_merge;
     pd.n_segs = plan->lane_n_segs;
+    pd.lane_stride = plan->lane_stride;
     pd.segs = plan->lane_segs.as<hdp::ThrSeg>();
     switch (plan->lane_n) {
       case 16: return launch_thr_lane<16>(pd, plan->lane_lds_bytes, x_dev, n_cells, out_dev, plan->opt_grid, stream, &plan->lane_tail);
@@ -2720,6 +2740,18 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
           tl[base + size_t(e2) * pitch + c] = (int32_t)(t * 4);
         }
       }
+    }
+    {  // regular columns: sample e2 of every column lies e2 * stride bytes behind its sample 0 (rows past S repeat S - 1)
+      int64_t stride = S >= 2 ? int64_t(tl[size_t(tl.size() ? 1 : 0) * (((ncols[0] + 63) / 64) * 64)]) - int64_t(tl[0]) : 0;
+      bool reg = S >= 2 && stride > 0 && stride < (int64_t(1) << 30);
+      for (int b = 0; reg && b < pl->n_blocks; ++b) {
+        const int pitch = ((ncols[b] + 63) / 64) * 64;
+        const int32_t *t0 = tl.data() + tloff[b];
+        for (int64_t e2 = 0; reg && e2 < lane_n; ++e2)
+          for (int c = 0; c < pitch; ++c)
+            if (int64_t(t0[size_t(e2) * pitch + c]) != int64_t(t0[c]) + std::min<int64_t>(e2, S - 1) * stride) { reg = false; break; }
+      }
+      pl->lane_stride = (reg && hdp::env_option("HDP_THR_STRIDE", 1) != 0) ? (int32_t)stride : 0;
     }
     if (T >= (int64_t(1) << 29)) pl->lane = false;  // byte offsets must fit 31 bits
     up(pl->tixl, tl.data(), tl.size() * 4);
