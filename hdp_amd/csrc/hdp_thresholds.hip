@@ -1182,7 +1182,12 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
     const int R = top ? (pair ? t.x - 1 : t.x) : (pd.n - 1 - t.x);
     const uint16_t *cl = pd.cols_local + size_t(row0 + r) * W;
 
-    int base[NC], lo[NC], hi[NC];
+    // Everything below is in LDS BYTE ADDRESSES (round 4): lo/hi/pos of column j are the addresses of its slots lo_j,
+    // hi_j, pos_j (slot 0 = the sentinel before the column), so a stride trip costs add, min, read, compare, select per
+    // column and nothing else -- the index form spent a sixth instruction on the address and, because the compiler kept
+    // the "this column does not move" test as a scalar mask, two scalar ones per column on top.
+    const uint32_t colk_a = uint32_t(uintptr_t(colk));
+    uint32_t lim[NC], lo[NC], hi[NC];
     RowFlags rf{0, 0};
     uint32_t nan_or = 0;
 #pragma unroll
@@ -1192,107 +1197,117 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
       nan_or |= f;
       rf.n_pos += (f >> 15) & 0x7fff;
       rf.n_neg += f & 0x7fff;
-      base[j] = c * pd.S_pad;
-      lo[j] = 0;
-      hi[j] = (j < W) ? min(S, R) : 0;  // no column holds more than the R keys ranked above the wanted one
+      lo[j] = colk_a + uint32_t(c * pd.S_pad) * 4u;
+      lim[j] = lo[j] + uint32_t(S + 1) * 4u;  // the sentinel after the column is never above
+      hi[j] = lo[j] + ((j < W) ? uint32_t(min(S, R)) * 4u : 0u);  // no column holds more than the R keys above the wanted one
     }
     if (nan_or >> 31) rf.n_pos = -1;
+    uint32_t sum_base = 0;  // G = (sum of pos - sum of slot-0 addresses) / 4
+#pragma unroll
+    for (int j = 0; j < NC; ++j) sum_base += lo[j];
+    const uint32_t R4 = uint32_t(R) * 4u + sum_base;  // the wanted sum of addresses
 
     // Round 1 (round 4 of the build): instead of the middle key of the widest interval -- for R = 3000 of 15 000 that is
-    // key 500 of a column, rank ~7500: several rounds go by just homing in -- the pivot is the key the wanted element is
-    // EXPECTED to be near: position R / W of the window's centre column (the centre day of the window is the most typical
-    // of its columns).  And after every count the distance |R - G| bounds every column's remaining move (no column can
-    // add or give back more keys than the pivot's rank missed by), so the intervals collapse to that width at once:
-    // 6.5 - 10 rounds and 34 - 50 stride trips per lane instead of 12 - 14 and 62 - 75 (bench generator, S = 1000).
+    // key 500 of a column, rank ~7500: several rounds go by just homing in -- the pivot is the value the wanted element is
+    // EXPECTED to be near: the MEAN over the window's columns of their keys at position R / W (one column's key there
+    // misses R by 60 - 180 in the count, the mean of W of them by a quarter of that).  And after every count the distance
+    // |R - G| bounds every column's remaining move (no column can add or give back more keys than the pivot's rank missed
+    // by), so the intervals collapse to that width at once.
     bool first = HDP_SELECT_WARM != 0;
     while (true) {
       // widest interval -> pivot (its middle key: the pivot's own interval at least halves every round)
-      int wj = 0, ww = hi[0] - lo[0], wlo = lo[0], wbase = base[0];
+      int wj = 0;
+      uint32_t ww = hi[0] - lo[0], wlo = lo[0];
 #pragma unroll
       for (int j = 1; j < NC; ++j) {
-        const int w = hi[j] - lo[j];
+        const uint32_t w = hi[j] - lo[j];
         const bool better = w > ww;
         ww = better ? w : ww;
         wj = better ? j : wj;
         wlo = better ? lo[j] : wlo;
-        wbase = better ? base[j] : wbase;
       }
-      if (ww <= 0) break;
-      int mid = wlo + ((ww + 1) >> 1);  // in [lo + 1, hi]
-      if (first) {  // every interval is still [0, min(S, R)]: any column may supply the pivot
-        const int wc = (W - 1) >> 1;  // centre of the row's column list
+      if (ww == 0) break;
+      uint32_t mid = wlo + ((((ww >> 2) + 1) >> 1) << 2);  // slot in [lo + 1, hi]
+      int pkey;
+      bool vp = false;  // this round's pivot is a value between keys, not a key
+      if (first) {
+        const uint32_t m4 = uint32_t(min(max((R + (W >> 1)) / W, 1), int(ww >> 2))) * 4u;
+        float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < NC; ++j)
-          if (j == wc) { wj = j; wbase = base[j]; }
-        mid = min(max((R + (W >> 1)) / W, 1), ww);
+        for (int j = 0; j < NC; ++j) acc += (j < W) ? key_f32(int(lds_u32(lo[j] + m4))) : 0.f;
+        pkey = f32_key(acc / float(W));
+        vp = true;
+        wj = NC;  // no column holds the pivot
         first = false;
+      } else {
+        pkey = int(lds_u32(mid));
       }
-      const int pkey = colk[wbase + mid];
       // Per column: c_j = number of keys ranked above the pivot.  lo_j <= c_j <= hi_j is known, so a
       // descent in power-of-two strides from lo_j finds it without looking at hi_j: key > thr[j] is
       // "ranked above the pivot" (an equal key of an earlier column ranks above it, of a later column
       // below it); the pivot's own column and the padding columns never move.
-      int pos[NC], thr[NC];
+      uint32_t pos[NC];
+      int thr[NC];
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
         const bool fixed = (j == wj) || (j >= W);
-        pos[j] = (j == wj) ? mid - 1 : lo[j];
-        thr[j] = fixed ? 0x7fffffff : pkey - ((j < wj) ? 1 : 0);
+        pos[j] = (j == wj) ? mid - 4u : lo[j];
+        thr[j] = fixed ? 0x7fffffff : pkey - ((j < wj && !vp) ? 1 : 0);
+        asm volatile("" : "+v"(thr[j]));  // a plain register operand: no per-column scalar mask in the stride loop
       }
       int nb = 11;  // strides 2^(nb-1) .. 1 cover every interval of the wave's lanes
-      while (nb > 0 && __ballot((ww >> (nb - 1)) != 0) == 0) --nb;
+      while (nb > 0 && __ballot((ww >> (nb + 1)) != 0) == 0) --nb;
       for (int sb = nb - 1; sb >= 0; --sb) {
-        const int stride = 1 << sb;
+        const uint32_t stride = 4u << sb;
         // all NC reads of a stride in flight before the first compare (the scheduler otherwise may pair every
         // read with its own wait, which exposes the LDS latency NC times per stride: 147 k -> 222 k cycles per block)
-        int idx[NC], k[NC];
+        uint32_t idx[NC];
+        int k[NC];
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-          idx[j] = min(pos[j] + stride, S + 1);  // the sentinel after the column is never above
-          k[j] = colk[base[j] + idx[j]];
+          idx[j] = min(pos[j] + stride, lim[j]);
+          k[j] = int(lds_u32(idx[j]));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NC; ++j) pos[j] = (k[j] > thr[j]) ? idx[j] : pos[j];
         __builtin_amdgcn_sched_barrier(0);
       }
-      int G = 0;
+      uint32_t G4 = 0;
 #pragma unroll
-      for (int j = 0; j < NC; ++j) G += pos[j];
-      if (G == R) {  // the pivot is the wanted element
+      for (int j = 0; j < NC; ++j) G4 += pos[j];
+      if (G4 == R4) {  // the pivot is the wanted element
 #pragma unroll
         for (int j = 0; j < NC; ++j) lo[j] = hi[j] = pos[j];
-      } else if (G > R) {  // pivot ranked below it: at most these many keys of each column are above it ...
-        const int back = HDP_SELECT_WARM ? G - R : (1 << 30);  // ... and at most G - R fewer than above the pivot
+      } else if (G4 > R4) {  // pivot ranked below it: at most these many keys of each column are above it ...
+        const uint32_t back = HDP_SELECT_WARM ? G4 - R4 : (1u << 30);  // ... and at most G - R fewer than above the pivot
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
           hi[j] = pos[j];
-          lo[j] = max(lo[j], pos[j] - back);
+          lo[j] = max(int(lo[j]), int(pos[j] - back));  // LDS addresses are far below 2^31
         }
-      } else {  // pivot ranked above it (so the pivot itself counts in its own column)
-        const int fwd = HDP_SELECT_WARM ? R - G - 1 : (1 << 30);  // keys still to be placed once the pivot is counted
+      } else {  // pivot ranked above it (so the pivot, when it is a key, counts in its own column)
+        const uint32_t fwd = HDP_SELECT_WARM ? R4 - G4 - (vp ? 0u : 4u) : (1u << 30);  // keys still to be placed
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
-          lo[j] = pos[j] + ((j == wj) ? 1 : 0);
+          lo[j] = pos[j] + ((j == wj) ? 4u : 0u);
           hi[j] = min(hi[j], lo[j] + fwd);
         }
       }
     }
 
     // heads after the R keys above the wanted one
-    int a = kKeyMin, b = kKeyMin, aj = 0, abase = base[0], apos = 0;
+    int a = kKeyMin, b = kKeyMin;
+    uint32_t apos = lo[0];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      const int k = (j < W) ? colk[base[j] + lo[j] + 1] : kKeyMin;
+      const int k = (j < W) ? int(lds_u32(lo[j] + 4u)) : kKeyMin;
       const bool win = k > a;
       b = win ? a : max(b, k);
-      aj = win ? j : aj;
-      abase = win ? base[j] : abase;
-      apos = win ? lo[j] + 1 : apos;
+      apos = win ? lo[j] + 4u : apos;
       a = win ? k : a;
     }
-    (void)aj;
-    if (pair) b = max(b, colk[abase + apos + 1]);  // R + 1 <= n - 1 for a pair: apos + 1 <= S + 1 (the sentinel)
+    if (pair) b = max(b, int(lds_u32(apos + 4u)));  // R + 1 <= n - 1 for a pair: at most the sentinel's slot S + 1
     const float fa = key_f32(a), fb = key_f32(b);
     const QuantileParam qp = pd.qp[p];
     const float q_hi = fa, q_lo = pair ? fb : fa;
