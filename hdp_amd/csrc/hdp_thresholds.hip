@@ -1166,6 +1166,12 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
 #ifndef HDP_SELECT_WARM
 #define HDP_SELECT_WARM 1
 #endif
+#ifndef HDP_SELECT_VROUNDS
+#define HDP_SELECT_VROUNDS 4  // value-pivot rounds before the pops
+#endif
+#ifndef HDP_SELECT_POPMAX
+#define HDP_SELECT_POPMAX 8  // a miss of at most this many keys is popped, not bisected
+#endif
 template <int NC>
 __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, const uint32_t *flags, int row0,
                                             int nrows, int tid, int64_t cell, double *__restrict__ out) {
@@ -1207,13 +1213,155 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
     for (int j = 0; j < NC; ++j) sum_base += lo[j];
     const uint32_t R4 = uint32_t(R) * 4u + sum_base;  // the wanted sum of addresses
 
-    // Round 1 (round 4 of the build): instead of the middle key of the widest interval -- for R = 3000 of 15 000 that is
-    // key 500 of a column, rank ~7500: several rounds go by just homing in -- the pivot is the value the wanted element is
-    // EXPECTED to be near: the MEAN over the window's columns of their keys at position R / W (one column's key there
-    // misses R by 60 - 180 in the count, the mean of W of them by a quarter of that).  And after every count the distance
-    // |R - G| bounds every column's remaining move (no column can add or give back more keys than the pivot's rank missed
-    // by), so the intervals collapse to that width at once.
-    bool first = HDP_SELECT_WARM != 0;
+    // ---- value rounds + pops (round 4 of the build) ----------------------------------------------------------------
+    // The pivot of these rounds is a VALUE v, not a key: count G(v) = keys above v over the window, and G - R is how far v
+    // missed.  Round 1 takes the mean over the window's columns of their keys at the expected position R / W; round 2 moves
+    // v by the mean distance to the keys (G - R) / W slots further along the columns v actually cuts; later rounds are
+    // secant steps on G(v), which is smooth at this scale (15 000 samples): |G - R| goes 115 .. 850 -> 10 .. 60 -> 2 .. 25
+    // -> 2 -> 1 on the bench generator.  After every count the miss bounds every column's remaining move, so the
+    // intervals -- and with them the number of strides -- collapse to that width at once.  When the miss is down to a
+    // few keys the lane does not bisect on (closing fifteen intervals of width 1 - 2 with key pivots took five to eight
+    // more rounds, and a wave runs as long as its slowest lane): it POPS that many keys off the W heads, forwards or
+    // backwards, with the heads packed into doubles (key in the high bits, LDS address in the low ones) so the best head
+    // and its column come out of one chain of v_max_f64.  Whatever is still open after that -- ties by the thousand,
+    // infinities in the mean, a stalled secant -- goes through the key-pivot loop below, which always terminates.
+    constexpr int kValueRounds = HDP_SELECT_VROUNDS, kPopMax = HDP_SELECT_POPMAX;
+    uint32_t pos[NC];
+    if (HDP_SELECT_WARM) {
+      float v, v0 = 0.f;
+      int e = 0, e0 = 0;
+      {
+        const uint32_t m4 = uint32_t(min(max((R + (W >> 1)) / W, 1), min(S, R))) * 4u;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) acc += (j < W) ? key_f32(int(lds_u32(lo[j] + m4))) : 0.f;
+        v = acc / float(W);
+      }
+      for (int k = 0; k < kValueRounds; ++k) {
+        uint32_t ww = 0;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) ww = max(ww, hi[j] - lo[j]);
+        const bool open = ww != 0;
+        if (__ballot(open) == 0) break;
+        const int pkey = f32_key(v);
+        int thr[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          pos[j] = lo[j];
+          thr[j] = (j < W) ? pkey : 0x7fffffff;
+          asm volatile("" : "+v"(thr[j]));
+        }
+        int nb = 11;
+        while (nb > 0 && __ballot(open && (ww >> (nb + 1)) != 0) == 0) --nb;
+        for (int sb = nb - 1; sb >= 0; --sb) {
+          const uint32_t stride = 4u << sb;
+          uint32_t idx[NC];
+          int kk[NC];
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            idx[j] = min(pos[j] + stride, lim[j]);
+            kk[j] = int(lds_u32(idx[j]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NC; ++j) pos[j] = (kk[j] > thr[j]) ? idx[j] : pos[j];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t G4 = 0;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) G4 += pos[j];
+        if (open) {
+          // A column whose count lies past its interval stops at the end of the stride range, at or past hi_j: G is then
+          // an underestimate, but only on the side where that keeps every conclusion below valid.
+          e0 = e;
+          e = int(G4 - R4);
+          if (e == 0) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) lo[j] = hi[j] = pos[j];
+          } else if (e > 0) {  // v ranks below the wanted key
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+              hi[j] = min(hi[j], pos[j]);
+              lo[j] = uint32_t(max(int(lo[j]), int(pos[j]) - e));
+            }
+          } else {  // v ranks above it
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+              lo[j] = pos[j];
+              hi[j] = min(hi[j], pos[j] + uint32_t(-e));
+            }
+          }
+          float vn = v;
+          if (k == 0) {
+            // the keys (G - R) / W slots from where v cuts each column, in the direction v has to move; columns v does not
+            // cut (none or all of their keys above it) have no say, and the step is scaled up for their absence
+            const int sh4 = ((e + (e > 0 ? 4 * W - 1 : -(4 * W - 1))) / (4 * W)) * 4;  // bytes, away from zero
+            float acc = 0.f;
+            int nroom = 0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+              const uint32_t slot = pos[j] - uint32_t(sh4);
+              const uint32_t first = lim[j] - uint32_t(S) * 4u;  // slot 1
+              const bool room = (j < W) && pos[j] >= first && pos[j] < lim[j] - 4u && slot >= first && slot < lim[j];
+              const float kf = key_f32(int(lds_u32(room ? slot : first)));
+              acc += room ? kf - v : 0.f;
+              nroom += room ? 1 : 0;
+            }
+            if (nroom > 0) vn = v + acc * float(W) / (float(nroom) * float(nroom));
+          } else {
+            const float dG = float(e - e0);
+            if (dG != 0.f) vn = v - float(e) * (v - v0) / dG;
+          }
+          if (!(vn == vn)) vn = v;
+          v0 = v;
+          v = vn;
+        }
+        if (k >= 1 && __ballot(open && e != 0 && abs(e) > kPopMax * 4) == 0) break;
+      }
+      // pops: |e| / 4 keys to add (e < 0, from the heads after pos) or to give back (e > 0, from the keys at pos)
+      uint32_t wl = 0;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) wl = max(wl, hi[j] - lo[j]);
+      const bool popl = wl != 0 && e != 0 && abs(e) <= kPopMax * 4;
+      if (__ballot(popl) != 0) {
+        const bool fwd = e < 0;
+        const int n = popl ? (abs(e) >> 2) : 0;
+        const uint32_t flip = fwd ? 0u : 0xffffffffu;  // backwards the smallest key goes first: ~key reverses the order
+        const uint32_t step = fwd ? 4u : uint32_t(-4);
+        // an int as a double is exact and leaves its low 22 bits clear: 18 of address and 4 of column number, which keeps
+        // the packed heads of a window that lists one column twice (the days past the year's end do) apart
+        auto pack = [](int key, uint32_t addr) {
+          const double d = double(key);
+          return __hiloint2double(__double2hiint(d), int(uint32_t(__double2loint(d)) | addr));
+        };
+        double hk[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          const uint32_t ad = pos[j] + (fwd ? 4u : 0u);
+          const int key = int(lds_u32(ad) ^ flip);
+          hk[j] = (j < W) ? pack(key, ad | uint32_t(j) << 18) : pack(int(0x80000000), 0u);
+        }
+        for (int i = 0; __ballot(i < n) != 0; ++i) {
+          double best = hk[0];
+#pragma unroll
+          for (int j = 1; j < NC; ++j) best = pk_max(best, hk[j]);
+          const uint32_t bl = uint32_t(__double2loint(best));
+          const uint32_t na = (bl & 0x3ffffu) + step;
+          const double nw = pack(int(lds_u32(na) ^ flip), na | (bl & 0x3c0000u));
+          const uint32_t match = (i < n) ? bl : 0xffffffffu;  // no packed low word is all ones (addresses end below 2^18)
+#pragma unroll
+          for (int j = 0; j < NC; ++j) hk[j] = (uint32_t(__double2loint(hk[j])) == match) ? nw : hk[j];
+        }
+        if (popl) {
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            const uint32_t ad = uint32_t(__double2loint(hk[j])) & 0x3ffffu;
+            if (j < W) lo[j] = hi[j] = fwd ? ad - 4u : ad;
+          }
+        }
+      }
+    }
+
     while (true) {
       // widest interval -> pivot (its middle key: the pivot's own interval at least halves every round)
       int wj = 0;
@@ -1227,26 +1375,13 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
         wlo = better ? lo[j] : wlo;
       }
       if (ww == 0) break;
-      uint32_t mid = wlo + ((((ww >> 2) + 1) >> 1) << 2);  // slot in [lo + 1, hi]
-      int pkey;
-      bool vp = false;  // this round's pivot is a value between keys, not a key
-      if (first) {
-        const uint32_t m4 = uint32_t(min(max((R + (W >> 1)) / W, 1), int(ww >> 2))) * 4u;
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) acc += (j < W) ? key_f32(int(lds_u32(lo[j] + m4))) : 0.f;
-        pkey = f32_key(acc / float(W));
-        vp = true;
-        wj = NC;  // no column holds the pivot
-        first = false;
-      } else {
-        pkey = int(lds_u32(mid));
-      }
+      const uint32_t mid = wlo + ((((ww >> 2) + 1) >> 1) << 2);  // slot in [lo + 1, hi]
+      const int pkey = int(lds_u32(mid));
+      constexpr bool vp = false;
       // Per column: c_j = number of keys ranked above the pivot.  lo_j <= c_j <= hi_j is known, so a
       // descent in power-of-two strides from lo_j finds it without looking at hi_j: key > thr[j] is
       // "ranked above the pivot" (an equal key of an earlier column ranks above it, of a later column
       // below it); the pivot's own column and the padding columns never move.
-      uint32_t pos[NC];
       int thr[NC];
 #pragma unroll
       for (int j = 0; j < NC; ++j) {
