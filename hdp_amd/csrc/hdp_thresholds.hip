@@ -1167,10 +1167,16 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
 #define HDP_SELECT_WARM 1
 #endif
 #ifndef HDP_SELECT_VROUNDS
-#define HDP_SELECT_VROUNDS 4  // value-pivot rounds before the pops
+#define HDP_SELECT_VROUNDS 6  // value-pivot rounds at most
+#endif
+#ifndef HDP_SELECT_POPGO
+#define HDP_SELECT_POPGO 16  // another value round while any lane of the wave misses by more than this
 #endif
 #ifndef HDP_SELECT_POPMAX
-#define HDP_SELECT_POPMAX 8  // a miss of at most this many keys is popped, not bisected
+#define HDP_SELECT_POPMAX 16  // a miss of at most this many keys is popped, not bisected
+// (rounds, go, max) on 4096 C5 cells: (4, 8, 8) 14.1 ms, (4, 16, 16) 13.1, (5, 16, 16) 12.6, (6, 16, 16) 12.5, (8, 16, 16) 12.5,
+// (6, 4, 16) 13.1, (6, 16, 32) 12.5, (4, 64, 64) 14.3: the secant stalls at a few keys, and a lane left to the key pivots
+// holds its whole wave
 #endif
 template <int NC>
 __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, const uint32_t *flags, int row0,
@@ -1225,7 +1231,7 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
     // backwards, with the heads packed into doubles (key in the high bits, LDS address in the low ones) so the best head
     // and its column come out of one chain of v_max_f64.  Whatever is still open after that -- ties by the thousand,
     // infinities in the mean, a stalled secant -- goes through the key-pivot loop below, which always terminates.
-    constexpr int kValueRounds = HDP_SELECT_VROUNDS, kPopMax = HDP_SELECT_POPMAX;
+    constexpr int kValueRounds = HDP_SELECT_VROUNDS, kPopMax = HDP_SELECT_POPMAX, kPopGo = HDP_SELECT_POPGO;
     uint32_t pos[NC];
     if (HDP_SELECT_WARM) {
       float v, v0 = 0.f;
@@ -1316,7 +1322,7 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
           v0 = v;
           v = vn;
         }
-        if (k >= 1 && __ballot(open && e != 0 && abs(e) > kPopMax * 4) == 0) break;
+        if (k >= 1 && __ballot(open && e != 0 && abs(e) > kPopGo * 4) == 0) break;
       }
       // pops: |e| / 4 keys to add (e < 0, from the heads after pos) or to give back (e > 0, from the keys at pos)
       uint32_t wl = 0;
@@ -1500,7 +1506,7 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
       // batches of kLoadBatch independent (list entry -> sample -> LDS) chains per thread: all list
       // reads of a batch are issued before the first sample read, all sample reads before the first
       // LDS write, so a thread keeps kLoadBatch HBM requests in flight instead of one
-      constexpr int kLoadBatch = 8;
+      constexpr int kLoadBatch = 24;  // 8 -> 24: the C5 load phase is six dependent list -> sample rounds shorter (-5.6 % per step)
       for (int base = tid; base < llen; base += kThrThreads * kLoadBatch) {
         int2 e[kLoadBatch];
         float v[kLoadBatch];

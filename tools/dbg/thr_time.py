@@ -34,3 +34,4 @@ for it in range(8):
     e1.record()
     torch.cuda.synchronize()
     print(f"iter {it}: {e0.elapsed_time(e1):.3f} ms for {n} cells  (checksum {float(out.sum()):.6f})")
+del plan
