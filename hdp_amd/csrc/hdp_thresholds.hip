@@ -309,19 +309,27 @@ template <int EPL>
 __device__ __forceinline__ void sort_column(float *col, int S, uint32_t *flag_out, int lane) {
   float v[EPL];
   uint32_t n_nan = 0, n_pos = 0, n_neg = 0;
+  bool special = false;  // exponent all ones: NaN or infinity (rare; counted only when present)
 #pragma unroll
   for (int r = 0; r < EPL; ++r) {
     // a sorting network does not care which slot an input starts in: read with consecutive lanes on consecutive
     // words (conflict-free) although the sorted output is lane-major
     const int e = r * 64 + lane;
-    float x = (e < S) ? col[e] : -INFINITY;
-    const bool is_nan = (x != x);
-    const bool is_pos = (e < S) && (x == INFINITY);
-    const bool is_neg = (e < S) && (x == -INFINITY);
-    n_nan += __popcll(__ballot(is_nan));
-    n_pos += __popcll(__ballot(is_pos));
-    n_neg += __popcll(__ballot(is_neg));
-    v[r] = is_nan ? 0.0f : x;
+    const float x = col[min(e, S - 1)];
+    special |= (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u;
+    v[r] = (e < S) ? x : -INFINITY;
+  }
+  if (__ballot(special) != 0) {  // wave-uniform
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+      const int e = r * 64 + lane;
+      const float x = v[r];
+      const bool is_nan = (x != x);
+      n_nan += __popcll(__ballot(is_nan));
+      n_pos += __popcll(__ballot((e < S) && (x == INFINITY)));
+      n_neg += __popcll(__ballot((e < S) && (x == -INFINITY)));
+      v[r] = is_nan ? 0.0f : x;
+    }
   }
   bitonic_desc_lm<EPL>(v, lane);
 #pragma unroll
@@ -1178,6 +1186,33 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
 // (6, 4, 16) 13.1, (6, 16, 32) 12.5, (4, 64, 64) 14.3: the secant stalls at a few keys, and a lane left to the key pivots
 // holds its whole wave
 #endif
+// pos[j] = key[j] > thr[j] ? idx[j] : pos[j] for all NC columns.  Written out by threes when NC allows: the compiler pairs
+// every v_cmp with its v_cndmask and has to put two idle states between them (a VALU-written mask may not be read by
+// the next two VALU instructions on gfx950); compare, compare, compare, select, select, select needs none.
+template <int NC>
+__device__ __forceinline__ void take_if_above(uint32_t (&pos)[NC], const uint32_t (&idx)[NC], const int (&key)[NC],
+                                              const int (&thr)[NC]) {
+  if constexpr (NC % 3 == 0) {
+#pragma unroll
+    for (int j = 0; j < NC; j += 3) {
+      unsigned long long m0, m1, m2;
+      asm volatile(
+          "v_cmp_gt_i32_e64 %[m0], %[k0], %[t0]\n\t"
+          "v_cmp_gt_i32_e64 %[m1], %[k1], %[t1]\n\t"
+          "v_cmp_gt_i32_e64 %[m2], %[k2], %[t2]\n\t"
+          "v_cndmask_b32_e64 %[p0], %[p0], %[i0], %[m0]\n\t"
+          "v_cndmask_b32_e64 %[p1], %[p1], %[i1], %[m1]\n\t"
+          "v_cndmask_b32_e64 %[p2], %[p2], %[i2], %[m2]"
+          : [p0] "+v"(pos[j]), [p1] "+v"(pos[j + 1]), [p2] "+v"(pos[j + 2]), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
+          : [k0] "v"(key[j]), [k1] "v"(key[j + 1]), [k2] "v"(key[j + 2]), [t0] "v"(thr[j]), [t1] "v"(thr[j + 1]),
+            [t2] "v"(thr[j + 2]), [i0] "v"(idx[j]), [i1] "v"(idx[j + 1]), [i2] "v"(idx[j + 2]));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) pos[j] = (key[j] > thr[j]) ? idx[j] : pos[j];
+  }
+}
+
 template <int NC>
 __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, const uint32_t *flags, int row0,
                                             int nrows, int tid, int64_t cell, double *__restrict__ out) {
@@ -1269,8 +1304,7 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
             kk[j] = int(lds_u32(idx[j]));
           }
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < NC; ++j) pos[j] = (kk[j] > thr[j]) ? idx[j] : pos[j];
+          take_if_above<NC>(pos, idx, kk, thr);
           __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t G4 = 0;
@@ -1410,8 +1444,7 @@ __device__ __forceinline__ void select_rows(const ThrDev &pd, const int *colk, c
           k[j] = int(lds_u32(idx[j]));
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NC; ++j) pos[j] = (k[j] > thr[j]) ? idx[j] : pos[j];
+        take_if_above<NC>(pos, idx, k, thr);
         __builtin_amdgcn_sched_barrier(0);
       }
       uint32_t G4 = 0;
