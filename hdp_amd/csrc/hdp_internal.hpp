@@ -178,8 +178,9 @@ struct hdp_metrics_plan {
 
 namespace hdp {
 // kernel launchers (defined in the .hip files)
+// x_pitch > 0: elements between the series of consecutive cells (default: T)
 int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_t n_cells,
-                      double *out_dev, hipStream_t stream);
+                      double *out_dev, hipStream_t stream, int64_t x_pitch = 0);
 // tm_pitch > 0: x_dev is time-major [T][tm_pitch] (element (t, c) at x_dev[t * tm_pitch + c]), else series-major
 int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const double *thr_dev,
                    int64_t n_thr_cells, const uint8_t *is_south_dev, int64_t n_cells,
@@ -213,8 +214,9 @@ int launch_weighted_row_mean_i16(const int16_t *v_dev, int64_t n_rows, int64_t n
                                  double *out_dev, hipStream_t stream);
 int launch_weighted_row_mean_f64(const double *v_dev, int64_t n_rows, int64_t n, const double *w_dev,
                                  double *out_dev, hipStream_t stream);
+// dst_pitch > 0: elements between consecutive series of the destination (default: T)
 int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
-                     hipStream_t stream, bool beside_state_machines = false);
+                     hipStream_t stream, bool beside_state_machines = false, int64_t dst_pitch = 0);
 int launch_swap_last2_f64(const double *src_dev, int64_t n, int64_t A, int64_t B, double *dst_dev,
                           hipStream_t stream);
 int launch_metrics_repack(const int16_t *dev_layout, int64_t P, int64_t D, int64_t n_cells, int64_t Y,

@@ -39,6 +39,7 @@ struct MetDev {
   const int32_t *defs;      // [D][3]
   const int2 *seasons;      // [2][Y]
   int T, n_doy, D, Y, P, Ypitch, n_groups, np_max, n_doy_pad;
+  int64_t xp;  // elements from one series to the next (T, or the padded pitch of the time-major staging)
   int seas_bytes, thr_bytes, wave_bytes;  // LDS carve, all multiples of 16
   int dmax;                                // max over definitions of max(min_duration, 1)
   int debug;                               // timing ablations only (HDP_METRICS_DEBUG): 1 = no stage B, 2 = no stage A
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(kMetWaves * 64) void metrics_kernel_general(
   st.si = 0; st.hwf = st.hwn = st.hwd = st.cur = 0; st.last_id = 0;
   st.acc_f = st.acc_n = st.acc_d = st.acc_a = 0;
 
-  const float *xc = x + cell * int64_t(md.T);
+  const float *xc = x + cell * md.xp;
   const int n_words = md.n_words;
 
   for (int w0 = 0; w0 < n_words; w0 += kChunkWords) {
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void exceed_kernel(MetDev md, const float *__r
         thr32[doy * PQ + q] = f64_to_f32_down(tc[int64_t(min(q, md.P - 1)) * md.n_doy + doy]);
   }
   __syncthreads();
-  const float *xc = x + cell * int64_t(md.T);
+  const float *xc = x + cell * md.xp;
   const int n_words = md.n_words;
   const int Tp = n_words * 64;
   unsigned long long *brow = md.bits_g + cell * md.P * int64_t(md.words_pad);
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void exceed_pairs_kernel(MetDev md, const floa
         thr32[doy * PP + q] = f64_to_f32_down(tc[int64_t(min(q, md.P - 1)) * md.n_doy + doy]);
   }
   __syncthreads();
-  const float *xc = x + cell * int64_t(md.T);
+  const float *xc = x + cell * md.xp;
   const int n_words = md.n_words;
   const int Tp = n_words * 64;
   unsigned long long *brow = md.bits_g + cell * md.P * int64_t(md.words_pad);
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64) void exceed_years_kernel(MetDev md, const float
       for (int q = 0; q < NP; ++q) th[j][q] = f64_to_f32_down(tc[int64_t(q) * n_doy + doy]);
     }
   }
-  const float *xc = x + cell * int64_t(T);
+  const float *xc = x + cell * md.xp;
   unsigned long long *rows[NP];  // wave-uniform row bases
 #pragma unroll
   for (int q = 0; q < NP; ++q) rows[q] = md.bits_g + (cell * md.P + p0 + q) * int64_t(md.words_pad);
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(kMetWaves * 64, 6) void metrics_kernel_uniform(
     }                                                                                               \
   } while (0)
 
-  const float *xc = x + cell * int64_t(md.T);
+  const float *xc = x + cell * md.xp;
   const int n_words = md.n_words;
 
   // run-skip shortcut: usable for 2 <= min_duration <= 32 (the look-ahead is one 32-day word)
@@ -1622,7 +1623,7 @@ int launch_weighted_row_mean_f64(const double *v_dev, int64_t n_rows, int64_t n,
 // 64 x 64 tiles through LDS (pitch 65: conflict-free both ways); reads are coalesced along the
 // cell axis, writes along time.  HBM-bound: 8 bytes of traffic per element.
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, int64_t src_pitch,
-                                                        int64_t T, int64_t n, float *__restrict__ dst) {
+                                                        int64_t T, int64_t n, float *__restrict__ dst, int64_t dp) {
   // 32 time steps x 64 cells per workgroup: 8.3 KB of LDS, so the copy fits beside the whole-cell thresholds
   // kernel (143 KB of a CU's 160 KB) and runs WHILE it computes; rows of 256 B in, 128 B out
   __shared__ float tile[32][65];
@@ -1638,7 +1639,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t c = c0 + cy + 8 * i, t = t0 + tx;
-    if (t < T && c < n) dst[c * T + t] = tile[tx][cy + 8 * i];
+    if (t < T && c < n) dst[c * dp + t] = tile[tx][cy + 8 * i];
   }
 }
 
@@ -1650,7 +1651,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // workgroup, landing in registers), then feeds them through the same 8.3 KB tile 32 time steps at a time.
 template <int NL>
 __global__ __launch_bounds__(256) void transpose_mlp_kernel(const float *__restrict__ src, int64_t src_pitch,
-                                                            int64_t T, int64_t n, float *__restrict__ dst) {
+                                                            int64_t T, int64_t n, float *__restrict__ dst, int64_t dp) {
   static_assert(NL % 8 == 0, "sub-tiles of 32 time steps");
   __shared__ float tile[32][65];
   const int64_t t0 = int64_t(blockIdx.y) * (4 * NL), c0 = int64_t(blockIdx.x) * 64;
@@ -1671,7 +1672,7 @@ __global__ __launch_bounds__(256) void transpose_mlp_kernel(const float *__restr
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int64_t c = c0 + cy + 8 * i, t = t0 + 32 * s + tx;
-      if (t < T && c < n) dst[c * T + t] = tile[tx][cy + 8 * i];
+      if (t < T && c < n) dst[c * dp + t] = tile[tx][cy + 8 * i];
     }
     __syncthreads();
   }
@@ -1682,21 +1683,22 @@ __global__ __launch_bounds__(256) void transpose_mlp_kernel(const float *__restr
 // 48 loads in flight per thread.  Measured on 109 795 cells, three chunks (profiles/r03_tm_*): thresholds pass 23.1 ms
 // with the 8-load kernel, 21.2 / 20.8 ms with 24 / 48 loads; metrics pass 22.3 / 23.2 / 23.2 ms.
 int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
-                     hipStream_t stream, bool beside_state_machines) {
+                     hipStream_t stream, bool beside_state_machines, int64_t dst_pitch) {
   if (T * n == 0) return HDP_OK;
+  const int64_t dp = dst_pitch > 0 ? dst_pitch : T;
   static const int nl_env = (int)env_option("HDP_TM_LOADS", -1);  // loads in flight per thread (0: the 8-load kernel); A/B only
   const int nl = nl_env >= 0 ? nl_env : (beside_state_machines ? 0 : 48);
   const int tsteps = nl >= 48 ? 192 : (nl >= 24 ? 96 : (nl >= 16 ? 64 : 32));
   dim3 grid((unsigned)((n + 63) / 64), (unsigned)((T + tsteps - 1) / tsteps));
   HDP_REQUIRE(grid.y < 65536, HDP_EUNSUP, "time axis too long for the transpose launch");
   if (nl >= 48)
-    hipLaunchKernelGGL(transpose_mlp_kernel<48>, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+    hipLaunchKernelGGL(transpose_mlp_kernel<48>, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev, dp);
   else if (nl >= 24)
-    hipLaunchKernelGGL(transpose_mlp_kernel<24>, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+    hipLaunchKernelGGL(transpose_mlp_kernel<24>, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev, dp);
   else if (nl >= 16)
-    hipLaunchKernelGGL(transpose_mlp_kernel<16>, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+    hipLaunchKernelGGL(transpose_mlp_kernel<16>, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev, dp);
   else
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, src_dev, src_pitch, T, n, dst_dev, dp);
   HDP_HIP_TRY(hipGetLastError());
   return HDP_OK;
 }
@@ -1907,6 +1909,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   md.defs = plan->defs.as<int32_t>();
   md.seasons = plan->seasons.as<int2>();
   md.T = (int)plan->T;
+  md.xp = plan->T;
   md.n_doy = (int)plan->n_doy;
   md.D = (int)plan->D;
   md.Y = (int)plan->Y;
@@ -1962,6 +1965,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
   // stream its exceedance kernel runs on -- the only kernel that reads the measure -- so the copy of batch b + 1 runs
   // beside the state machines of batch b.  Smaller batches bound the staging (2 x batch x T x 4 bytes).
   const bool tm = tm_pitch > 0;
+  const int64_t Tp = (int64_t(md.T) + 31) & ~int64_t(31);  // staging rows padded to 128 bytes (launch_thresholds_tm has the measurement)
   HDP_REQUIRE(!tm || split, HDP_EUNSUP, "time-major input needs the split metrics path");
   if (tm) {
     int64_t cap = std::max<int64_t>(64, (int64_t(6) << 30) / (int64_t(md.T) * 4));
@@ -1987,7 +1991,7 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
     if (rc != HDP_OK) return rc;
   }
   if (tm) {
-    const int rc = grow(plan->tm_stage, 2 * size_t(batch) * md.T * 4, "time-major staging");
+    const int rc = grow(plan->tm_stage, 2 * size_t(batch) * size_t(Tp) * 4, "time-major staging");
     if (rc != HDP_OK) return rc;
   }
   if (!by_cells) {
@@ -2050,15 +2054,16 @@ int launch_metrics(const hdp_metrics_plan *plan, const float *x_dev, const doubl
                 "shared thresholds need batches aligned to the number of threshold cells");
     const double *thr_b = one_to_one ? thr_dev + c0 * int64_t(md.n_doy) * md.P : thr_dev;
     const int64_t ntc_b = one_to_one ? nc : n_thr_cells;
-    const float *x_b = tm ? plan->tm_stage.as<float>() + size_t(half) * size_t(batch) * md.T : x_dev + c0 * int64_t(md.T);
+    const float *x_b = tm ? plan->tm_stage.as<float>() + size_t(half) * size_t(batch) * size_t(Tp) : x_dev + c0 * int64_t(md.T);
     MetDev mb = md;
+    if (tm) mb.xp = Tp;
     mb.bits_g = md.bits_g + size_t(half) * size_t(batch) * (row_bytes / 8);
     hipStream_t sm = (overlap && half) ? plan->aux_stream2 : stream;  // stream of this batch's state machine
     if (split) {
       // this half of the scratch is free once the state machine of batch b - 2 has read it
       if (overlap && b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(sx, plan->ev_state[half], 0));
       if (tm) {  // staging half `half` was last read by the exceedance kernel of batch b - 2, earlier on this stream
-        const int rc = launch_transpose(x_dev + c0, tm_pitch, md.T, nc, const_cast<float *>(x_b), sx, true);
+        const int rc = launch_transpose(x_dev + c0, tm_pitch, md.T, nc, const_cast<float *>(x_b), sx, true, Tp);
         if (rc != HDP_OK) return rc;
       }
       if (HDP_MDBG(md, 8)) {  // ablation builds: state machines only, on the exceedance words of the previous call

@@ -67,6 +67,7 @@ struct ThrDev {
   int lane_stride;                             // lane kernel: bytes between consecutive samples of every column (0: irregular, use the table)
   int select;                                  // one-workgroup-per-cell kernel: rank selection instead of the merge
   int n_doy, S, W, P, T, S_pad, Wp, RP, n_blocks, ncols_max;
+  int64_t xp;  // elements from one cell's series to the next (T, or the padded pitch of the time-major staging)
   int steps_top, steps_bot, nt_top, nt_bot, n;
   // Timing ablations and instrumentation: compiled in only with -DHDP_DEBUG_ABLATIONS (a release build ignores
   // HDP_THR_DEBUG and carries none of this code).  Bit mask; results are wrong under 1, 2, 4:
@@ -1515,7 +1516,7 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
 
   const int64_t cell = blockIdx.x;
   if (cell >= n_cells) return;
-  const float *xc = x + cell * int64_t(pd.T);
+  const float *xc = x + cell * pd.xp;
 
   for (int b = 0; b < pd.n_blocks; ++b) {
     const int row0 = pd.blk_row0[b];
@@ -1812,7 +1813,7 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
       asm volatile("" : "+s"(S_rt));
       if (s < n_items) {
         const int64_t cell_p = first_cell + s * wg_per_blk;
-        const char *xc = reinterpret_cast<const char *>(x + cell_p * int64_t(pd.T));
+        const char *xc = reinterpret_cast<const char *>(x + cell_p * pd.xp);
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
           const int task = pw + k * n_prod;  // wave-uniform
@@ -2271,7 +2272,7 @@ extern "C" const char *hdp_threshold_plan_describe(const hdp_threshold_plan *pla
 }
 
 int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_t n_cells,
-                      double *out_dev, hipStream_t stream) {
+                      double *out_dev, hipStream_t stream, int64_t x_pitch) {
   if (n_cells == 0) return HDP_OK;
   HDP_REQUIRE(n_cells < (int64_t(1) << 31), HDP_EUNSUP, "n_cells %lld exceeds one launch",
               (long long)n_cells);
@@ -2293,6 +2294,7 @@ int launch_thresholds(const hdp_threshold_plan *plan, const float *x_dev, int64_
   pd.W = (int)plan->W;
   pd.P = (int)plan->P;
   pd.T = (int)plan->T;
+  pd.xp = x_pitch > 0 ? x_pitch : plan->T;
   pd.S_pad = plan->S_pad;
   pd.Wp = plan->Wp;
   pd.RP = plan->RP;
@@ -2365,9 +2367,15 @@ int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, 
                          double *out_dev, hipStream_t stream) {
   if (n_cells == 0) return HDP_OK;
   const int64_t T = plan->T;
-  const int64_t chunk = std::min<int64_t>(n_cells, std::max<int64_t>(256, (int64_t(5) << 30) / (T * 4)));
+  static const long long chunk_env = env_option("HDP_TM_CHUNK_CELLS", 0);  // A/B only
+  const int64_t chunk = std::min<int64_t>(n_cells, chunk_env > 0 ? chunk_env : std::max<int64_t>(256, std::min<int64_t>(8192, (int64_t(5) << 30) / (T * 4))));
   if (!plan->tm_stream) {
-    // the copy stream gets the highest priority: its workgroups are dispatched ahead of the next chunk's kernel
+    // The copy stream gets the LOWEST priority (round 4; it had the highest): a kernel-trace of the pipeline
+    // (tools/dbg/tm_time.py) shows a chunk's kernel and the next chunk's copy released at the same moment, the copy's
+    // workgroups filling every CU first, and the kernel taking its own time PLUS the copy's (1.24 against 0.69 ms per 8 192
+    // cells next to a 0.95 ms copy) -- time-slicing, not overlap.  With the kernel's workgroups placed first and chunks of
+    // 8 192 cells the pass is 9.6 instead of 10.3 ms per 65 536 cells (series-major 5.1); a copy in turns on one stream
+    // costs the same 10.3.
     int prio_lo = 0, prio_hi = 0;
     HDP_HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     // events first, the stream last: `tm_stream != nullptr` then means "everything exists" -- a failure half way leaves
@@ -2377,9 +2385,12 @@ int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, 
       if (!plan->tm_copied[i]) HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_copied[i], hipEventDisableTiming));
       if (!plan->tm_used[i]) HDP_HIP_TRY(hipEventCreateWithFlags(&plan->tm_used[i], hipEventDisableTiming));
     }
-    HDP_HIP_TRY(hipStreamCreateWithPriority(&plan->tm_stream, hipStreamNonBlocking, prio_hi));
+    HDP_HIP_TRY(hipStreamCreateWithPriority(&plan->tm_stream, hipStreamNonBlocking, prio_lo));
   }
-  const size_t need = 2 * size_t(chunk) * T * 4;
+  // staging rows are padded to a multiple of 128 bytes: with T * 4 = 146 000 (80 past a line) every 128-byte store of the
+  // copy straddled two lines and the copy ran at 3.6 TB/s; aligned (a 96-year record happens to be) it runs at 5.0
+  const int64_t Tp = (T + 31) & ~int64_t(31);
+  const size_t need = 2 * size_t(chunk) * Tp * 4;
   if (plan->tm_stage.bytes < need) {
     HDP_HIP_TRY(hipStreamSynchronize(stream));
     HDP_HIP_TRY(hipStreamSynchronize(plan->tm_stream));
@@ -2388,7 +2399,7 @@ int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, 
       return set_error(HDP_ENOMEM, "allocating %zu bytes of time-major staging failed: %s", need, hipGetErrorString(e));
   }
   if (g_reserve_only) {  // staging, stream and events exist now; the tiered image's tail for one chunk (nothing launches)
-    if (plan->lane && plan->lane_tier_k < plan->S) return launch_thresholds(plan, plan->tm_stage.as<float>(), chunk, out_dev, stream);
+    if (plan->lane && plan->lane_tier_k < plan->S) return launch_thresholds(plan, plan->tm_stage.as<float>(), chunk, out_dev, stream, Tp);
     return HDP_OK;
   }
   HDP_HIP_TRY(hipEventRecord(plan->tm_fork, stream));
@@ -2397,13 +2408,13 @@ int launch_thresholds_tm(const hdp_threshold_plan *plan, const float *x_tm_dev, 
   for (int64_t c0 = 0; c0 < n_cells; c0 += chunk, ++b) {
     const int64_t nc = std::min(chunk, n_cells - c0);
     const int half = int(b & 1);
-    float *stage = plan->tm_stage.as<float>() + size_t(half) * size_t(chunk) * T;
+    float *stage = plan->tm_stage.as<float>() + size_t(half) * size_t(chunk) * Tp;
     if (b >= 2) HDP_HIP_TRY(hipStreamWaitEvent(plan->tm_stream, plan->tm_used[half], 0));
-    int rc = launch_transpose(x_tm_dev + c0, pitch, T, nc, stage, plan->tm_stream);
+    int rc = launch_transpose(x_tm_dev + c0, pitch, T, nc, stage, plan->tm_stream, false, Tp);
     if (rc != HDP_OK) return rc;
     HDP_HIP_TRY(hipEventRecord(plan->tm_copied[half], plan->tm_stream));
     HDP_HIP_TRY(hipStreamWaitEvent(stream, plan->tm_copied[half], 0));
-    rc = launch_thresholds(plan, stage, nc, out_dev + c0 * plan->n_doy * plan->P, stream);
+    rc = launch_thresholds(plan, stage, nc, out_dev + c0 * plan->n_doy * plan->P, stream, Tp);
     if (rc != HDP_OK) return rc;
     HDP_HIP_TRY(hipEventRecord(plan->tm_used[half], stream));
   }
