@@ -1678,16 +1678,17 @@ __global__ __launch_bounds__(256) void transpose_mlp_kernel(const float *__restr
   }
 }
 
-// `beside_state_machines`: the copy will run next to the packed state machines, which leave 32 registers per SIMD -- the
-// 10-register kernel; otherwise (next to the whole-cell thresholds kernel: 80 registers per SIMD, or on an idle device)
-// 48 loads in flight per thread.  Measured on 109 795 cells, three chunks (profiles/r03_tm_*): thresholds pass 23.1 ms
-// with the 8-load kernel, 21.2 / 20.8 ms with 24 / 48 loads; metrics pass 22.3 / 23.2 / 23.2 ms.
+// `beside_state_machines`: the copy runs next to the packed state machines -- 24 loads in flight per thread; otherwise
+// (next to the whole-cell thresholds kernel, or on an idle device) 48.  Round 3 measured the 8-load kernel as the better
+// neighbour of the state machines (22.3 against 23.2 ms, 109 795 cells); with the staging rows padded to 128 bytes and
+// 331 k cells per call (round 4) the metrics pass takes 62.2 / 57.6 / 57.9 ms with 8 / 24 / 48 loads (series-major 41.7);
+// capping the state machines at six or five waves per SIMD to leave the copy registers changes nothing (58.2 - 58.4).
 int launch_transpose(const float *src_dev, int64_t src_pitch, int64_t T, int64_t n, float *dst_dev,
                      hipStream_t stream, bool beside_state_machines, int64_t dst_pitch) {
   if (T * n == 0) return HDP_OK;
   const int64_t dp = dst_pitch > 0 ? dst_pitch : T;
   static const int nl_env = (int)env_option("HDP_TM_LOADS", -1);  // loads in flight per thread (0: the 8-load kernel); A/B only
-  const int nl = nl_env >= 0 ? nl_env : (beside_state_machines ? 0 : 48);
+  const int nl = nl_env >= 0 ? nl_env : (beside_state_machines ? 24 : 48);
   const int tsteps = nl >= 48 ? 192 : (nl >= 24 ? 96 : (nl >= 16 ? 64 : 32));
   dim3 grid((unsigned)((n + 63) / 64), (unsigned)((T + tsteps - 1) / tsteps));
   HDP_REQUIRE(grid.y < 65536, HDP_EUNSUP, "time axis too long for the transpose launch");
