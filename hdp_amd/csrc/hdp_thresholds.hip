@@ -969,6 +969,9 @@ __device__ __forceinline__ void merge_both_lean(const ThrDev &pd, const unsigned
 // lane's C overshoots (more than `limit` samples before the pivot, so the run's first rank would be missed) the wave
 // takes a shallower pivot, at worst none (C = 0).  Lanes start from different ranks C; the wave counts ranks from the
 // smallest and a lane joins in when the count reaches its own, so emissions stay wave-uniform.
+#ifndef HDP_SEG_REFINE
+#define HDP_SEG_REFINE 1  // pivot refinement rounds of a segmented walk's entry (0: the host's pivot only)
+#endif
 template <bool TOP, int NG, int ROWS>
 __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg, const int2 *tgt, const unsigned char *image,
                                               unsigned char *strips, const uint16_t *cl, int r, const RowFlags &rf,
@@ -1007,8 +1010,33 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
   // ---- entry: slot of every column's first head, and the rank C the lane starts from
   uint32_t start[NC];
   int C = 0;
+  // pos_j = samples of column j ranked before v, by descent in strides from the column's own end; returns their sum.
+  // The columns are sorted descending: slot 1 the largest, slot S the smallest, sentinels at 0 and S + 1 (never "before"
+  // anything).  TOP: pos_j counts from slot 1 down;  bottom: pos_j counts from slot S up (slot S + 1 - idx).
+  auto count_before = [&](uint32_t v, uint32_t (&pos)[NC]) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) pos[j] = 0;
+    for (int stride = 64; stride >= 1; stride >>= 1) {  // S <= 100 in this kernel: 7 strides reach 127
+      uint32_t idx[NC], k[NC];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        idx[j] = min(pos[j] + uint32_t(stride), uint32_t(S + 1));
+        k[j] = lds_u32(cbase[j] + (TOP ? idx[j] : uint32_t(S + 1) - idx[j]) * 4u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NC; ++j) pos[j] = before(k[j], v) ? idx[j] : pos[j];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      if (j < W) c += int(pos[j]);
+    return c;
+  };
   {
     int p = sg.pivot_pos;  // wave-uniform
+    float va = 0.0f;       // the accepted pivot (as a value)
     while (true) {
 #pragma unroll
       for (int j = 0; j < NC; ++j) start[j] = uint32_t(TOP ? 1 : S);
@@ -1026,35 +1054,70 @@ __device__ __forceinline__ void merge_row_seg(const ThrDev &pd, const ThrSeg &sg
           if (j < W) acc += __uint_as_float(lds_u32(cbase[j] + uint32_t(TOP ? p : S + 1 - p) * 4u));
         acc *= 1.0f / float(W);
         v = __float_as_uint(acc);
+        va = acc;
         if (acc != acc) v = TOP ? kRawMax : kRawMin;   // +inf and -inf in one window: enter at the end instead
       }
-      // pos_j = samples of column j ranked before v, by descent in strides from the column's own end.  The columns are
-      // sorted descending: slot 1 the largest, slot S the smallest, sentinels at 0 and S + 1 (never "before" anything).
-      //   TOP: pos_j counts from slot 1 down;  bottom: pos_j counts from slot S up (slot S + 1 - idx).
       uint32_t pos[NC];
+      C = count_before(v, pos);
 #pragma unroll
-      for (int j = 0; j < NC; ++j) pos[j] = 0;
-      for (int stride = 64; stride >= 1; stride >>= 1) {  // S <= 100 in this kernel: 7 strides reach 127
-        uint32_t idx[NC], k[NC];
-#pragma unroll
-        for (int j = 0; j < NC; ++j) {
-          idx[j] = min(pos[j] + uint32_t(stride), uint32_t(S + 1));
-          k[j] = lds_u32(cbase[j] + (TOP ? idx[j] : uint32_t(S + 1) - idx[j]) * 4u);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NC; ++j) pos[j] = before(k[j], v) ? idx[j] : pos[j];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int j = 0; j < NC; ++j) {
-        if (j < W) {
-          C += int(pos[j]);
-          start[j] = TOP ? pos[j] + 1u : uint32_t(S) - pos[j];
-        }
-      }
+      for (int j = 0; j < NC; ++j)
+        if (j < W) start[j] = TOP ? pos[j] + 1u : uint32_t(S) - pos[j];
       if (__ballot(C > sg.limit) == 0) break;  // every lane can still emit the run's first rank (with its predecessor)
       p -= max(2, p >> 3);                     // some lane overshot: a slightly shallower pivot for the whole wave
+    }
+    // ---- refinement (round 4, second build): the host's pivot leaves 3.5 standard deviations of head room, and the wave
+    // walks from its LOWEST lane's entry -- 112 steps before the run's first rank on average for the spread set, 140 for
+    // the median set: at ~300 cycles a step that was most of a run.  Every lane now moves its own pivot towards its limit:
+    // first by the mean distance to the keys (limit - slack - C) / W slots further along the columns it cuts, then by secant
+    // steps on the count; a candidate that overshoots the limit is dropped (it still serves the next secant step).  A
+    // round is one more count pass (7 strides: ~600 instructions, ~1 k cycles); it ends when every lane of the wave is
+    // within kEntryNear ranks of its limit.
+    if (p > 0 && HDP_SEG_REFINE > 0) {
+      constexpr int kEntryNear = 8, kSlack = 6;
+      float vb = 0.0f;
+      int Cb = 0;
+      bool have_b = false;
+      for (int it = 0; it < HDP_SEG_REFINE; ++it) {
+        const int gap = sg.limit - C;  // >= 0
+        if (__ballot(gap > kEntryNear) == 0) break;
+        const int target = sg.limit - (it == 0 ? max(kSlack, gap >> 2) : kSlack);
+        float vn = va;
+        if (gap > kEntryNear && va == va) {
+          if (!have_b) {
+            const int sh = (target - C + W - 1) / W;  // slots further along every column, >= 1
+            float acc = 0.0f;
+            int nroom = 0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+              const uint32_t pj = TOP ? start[j] - 1u : uint32_t(S) - start[j];  // samples of column j before the pivot
+              const uint32_t slot = pj + uint32_t(sh);                             // in walk order, 1-based
+              const bool room = (j < W) && pj >= 1u && pj < uint32_t(S) && slot <= uint32_t(S);
+              const float kf = __uint_as_float(lds_u32(cbase[j] + (TOP ? (room ? slot : 1u) : uint32_t(S + 1) - (room ? slot : 1u)) * 4u));
+              acc += room ? kf - va : 0.0f;
+              nroom += room ? 1 : 0;
+            }
+            if (nroom > 0) vn = va + acc * float(W) / (float(nroom) * float(nroom));
+          } else if (Cb != C) {
+            vn = va + float(target - C) * (vb - va) / float(Cb - C);
+          }
+          if (!(vn == vn) || fabsf(vn) == INFINITY) vn = va;
+        }
+        uint32_t pos[NC];
+        const int Cn = count_before(__float_as_uint(vn), pos);
+        const bool take = Cn <= sg.limit && Cn > C;
+        if (take || Cn != C) {  // the other point of the next secant step: the pivot left behind, or the one that overshot
+          vb = take ? va : vn;
+          Cb = take ? C : Cn;
+          have_b = true;
+        }
+        if (take) {
+          va = vn;
+          C = Cn;
+#pragma unroll
+          for (int j = 0; j < NC; ++j)
+            if (j < W) start[j] = TOP ? pos[j] + 1u : uint32_t(S) - pos[j];
+        }
+      }
     }
   }
   double m[NG];
