@@ -10,7 +10,7 @@ if os.environ.get('HDP_DBG_LIB'):
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 lib = _lib.ensure_device(0)
 dev = torch.device("cuda", 0)
-sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=int(os.environ.get("CORUN_PRIO", "0")))
 T = 36500
 dates = utils.noleap_date_range("2000-01-01", "2099-12-31")
 ti, cols = cal.window_columns(dates, 7)
