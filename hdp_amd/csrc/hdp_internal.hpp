@@ -102,8 +102,6 @@ struct hdp_threshold_plan {
   hdp::DevBuf qparam;      // QuantileParam [P]
   hdp::DevBuf tgt_top, tgt_bot;  // int2 (rank, slot) sorted by rank
   hdp::DevBuf blk_sort_off, sort_slots;  // per block: the LDS column slots it loads and sorts
-  // pipelined kernel (S <= 128): producer waves gather + sort the next block in registers while
-  // the merging waves work on the current one
   bool select_only = false;  // LDS sized without merge heads: only the rank-selection kernel can run this plan
   int32_t n_merge = 0;      // waves that merge (ceil(rows_per_block / 64)); the rest produce
   mutable hdp::DevBuf clk;       // HDP_THR_DEBUG=8 phase clocks (-DHDP_DEBUG_ABLATIONS builds only)

@@ -10,19 +10,19 @@
 // out of its W sorted columns and interpolate in float64 with numba's operation order,
 // lower*(1-m) + upper*m, no FMA contraction (this file is compiled with -ffp-contract=off).
 //
-// Four kernels, same results bit for bit (tests/test_thresholds_kernels_gpu.py); the plan picks one (thr_variant):
+// Three kernels, same results bit for bit (tests/test_thresholds_kernels_gpu.py); the plan picks one (thr_variant):
 //   thresholds_lane_kernel<N, NG, TIER, ROWS>   S <= 100, W <= 16 -- the headline config (S = 100, W = 15).  One LANE sorts
 //             one column in N registers (Batcher merge exchange, nothing crosses lanes); merging waves run a W-way
 //             merge per row (one lane per row) out of the LDS image of the previous item.  ROWS = 384 ("whole cell"): all
 //             365 columns and all 365 merge chains of a cell in one 12-wave workgroup per CU, the image tiered (top 60
 //             samples of a column in LDS, the rest in a per-workgroup global tail); ROWS = 128: blocks of rows, untiered.
-//   thresholds_pipe_kernel<LPC, VEC, NG>   100 < S <= 128, or windows wider than 16 columns.  Persistent workgroups,
-//             waves specialised: producers gather a block's columns straight from HBM into registers and sort them
-//             there (16-lane DPP rows, v_med3), merging waves as above.
-//   thresholds_kernel<EPL, false>          any S <= 2048: one workgroup per cell, load -> LDS,
+//             Walks that start deep (quantile sets away from the tail) are cut into runs that enter the merge at a pivot
+//             (merge_row_seg).
+//   thresholds_kernel<EPL, false>          any S <= 2048 (and windows wider than 15 columns): one workgroup per cell, load -> LDS,
 //             wave sort (lane-major bitonic network), W-way merge per row.
 //   thresholds_kernel<EPL, true>           the same with a rank SELECTION per (row, requested
-//             rank) instead of the merge, for deep ranks (10-member ensemble: S = 1000).
+//             rank) instead of the merge, for deep ranks (10-member ensemble: S = 1000): value-pivot rounds, then
+//             a popped finish (select_rows).
 // plus table_percentiles_kernel, the literal [n_doy, B] table path of the reference's gufunc operands (unit-level parity).
 //
 // This path is VALU/LDS (sort + merge) work, not MFMA work; its roofline is HBM bandwidth:
@@ -38,8 +38,8 @@ namespace hdp {
 
 struct ThrSeg {  // one run of requested ranks of a row (device-visible POD, 32 bytes)
   int32_t top;        // 1: descending merge (ranks counted from the largest sample), 0: ascending
-  int32_t pivot_pos;  // > 0: enter the merge at the value of the window's centre column at this position (1-based, from
-                      //      the walk's own end); 0: enter at the end of the window
+  int32_t pivot_pos;  // > 0: enter the merge at the mean of the window columns' samples at this position (1-based, from
+                      //      the walk's own end), refined once per lane; 0: enter at the end of the window
   int32_t limit;      // entry is valid while no more than this many samples rank before the pivot (first rank - 1)
   int32_t tgt_off;    // first target of the run in tgt_top / tgt_bot
   int32_t nt;         // targets of the run
@@ -72,7 +72,7 @@ struct ThrDev {
   // Timing ablations and instrumentation: compiled in only with -DHDP_DEBUG_ABLATIONS (a release build ignores
   // HDP_THR_DEBUG and carries none of this code).  Bit mask; results are wrong under 1, 2, 4:
   //   1 no merge, 2 no sort, 4 no sample loads, 8 phase clocks of the one-workgroup-per-cell kernel (forces it),
-  //   32 phase clocks of the pipelined kernel (merging wave / first producer), 512 with 32: start-up and step
+  //   32 phase clocks of the lane kernel (merging wave / first producer), 512 with 32: start-up and step
   //   loop of the merge instead of the producer phases, 64 roles by wave number instead of by SIMD, 1024 busy ticks of every wave of the lane kernel (by role rank),
   //   4096 print the kernel variant chosen.  The clocks cost about 10 % and serialise on global atomics.
   int debug;
@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
   float *colbuf = reinterpret_cast<float *>(smem + off);
   off += (size_t(pd.ncols_max) * pd.S_pad * 4 + 15) & ~size_t(15);
   uint32_t *flags = reinterpret_cast<uint32_t *>(smem + off);
-  off += 2 * ((size_t(pd.ncols_max) * 4 + 15) & ~size_t(15));  // second copy: pipelined kernel only
+  off += 2 * ((size_t(pd.ncols_max) * 4 + 15) & ~size_t(15));  // (the plan sizes two copies)
   float *hbuf = reinterpret_cast<float *>(smem + off);
   off += size_t(pd.Wp) * pd.RP * 4;
   uint32_t *posb = reinterpret_cast<uint32_t *>(smem + off);
@@ -1677,7 +1677,8 @@ __global__ __launch_bounds__(kThrThreads, SELECT ? 2 : 4) void thresholds_kernel
 // compare-exchanges per 64 columns against 4 x 450 instructions per 4 columns before: 3.3x fewer vector
 // instructions for the sort).  Loads are coalesced without any transposition: the samples of one year of 64
 // adjacent columns are 64 adjacent time steps.  The merging waves, the LDS image and the emission are the ones of
-// thresholds_pipe_kernel; results are bit-identical (tests/test_thresholds_kernels_gpu.py).
+// the round-2 pipelined kernel this one replaced; results are bit-identical to the one-workgroup-per-cell kernel
+// (tests/test_thresholds_kernels_gpu.py).
 constexpr int ilog2_ceil(int n) {
   int t = 0;
   while ((1 << t) < n) ++t;
@@ -1825,7 +1826,7 @@ __global__ __launch_bounds__(ROWS == kWholeRows ? kWholeThreads : kThrThreads, H
   for (int i = tid; i < pd.img_pitch; i += int(blockDim.x))
     colbuf[size_t(pd.ncols_max) * pd.img_pitch + i] = __uint_as_float(i <= 2 ? kRawMin : kRawMax);
 
-  // Roles by SIMD, as in thresholds_pipe_kernel: one merging wave per SIMD first.
+  // Roles by SIMD: one merging wave per SIMD first.
   const int n_merge = pd.n_merge;
   const int n_prod = nwaves - n_merge;
   __shared__ int s_simd[kWholeThreads / 64];
@@ -2618,12 +2619,12 @@ extern "C" int hdp_threshold_plan_create(const int64_t *time_index, int64_t n_do
   auto lds_for = [&](int rows, int ncols) -> size_t {
     const int RP = (rows + 63) & ~63;
     size_t b = (size_t(ncols) * spad * 4 + 15) & ~size_t(15);
-    b += 2 * ((size_t(ncols) * 4 + 15) & ~size_t(15));  // census words (x2: pipelined kernel)
+    b += 2 * ((size_t(ncols) * 4 + 15) & ~size_t(15));  // census words (x2)
     if (!pl->select_only) {
       b += size_t(pl->Wp) * RP * 4;  // heads
       b += size_t(pl->Wp) * RP * 4;  // position | slot payloads
     }
-    b += (size_t(rows) * W * 2 + 15) & ~size_t(15);  // window column lists (pipelined kernel)
+    b += (size_t(rows) * W * 2 + 15) & ~size_t(15);  // window column lists
     return b;
   };
   auto cols_of_block = [&](int row0, int rows, std::vector<int> &set) {
