@@ -1037,8 +1037,13 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t bsel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
 struct CPair {  // two definitions' state, one per 16-bit half
-  uint32_t hw, subs, id;  // hw: 0xffff while a heatwave is active
-  uint32_t hwf, hwn, hwd, cur, last_id;
+  uint32_t hw, subs;  // hw: 0xffff while a heatwave is active
+  // fresh: 0xffff while the current heatwave has not been credited in the current season yet.  The reference numbers
+  // its heatwaves (id) and counts one when a credited run's id differs from the last credited one (last_id, reset with
+  // the season): "differs" is exactly "a heatwave started, or the season changed, since the last credit" -- one flag
+  // instead of two counters, one instruction instead of four for `first` (round 4).
+  uint32_t fresh;
+  uint32_t hwf, hwn, hwd, cur;
 };
 
 #ifndef HDP_C16_WAVES
@@ -1107,17 +1112,18 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
     }
     CPair st[NP];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) st[k] = CPair{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < NP; ++k) st[k] = CPair{0, 0, 0xffffffffu, 0, 0, 0, 0};
     int open = 0, s_open = 0, e_prev = -(1 << 30);
 
     // `lab`: 0xffff in the halves whose definition labels the run; days > 0 of it fall inside the current season
-    auto credit_k = [&](CPair &c, uint32_t lab, uint32_t run_id, int days) {
+    // `fresh_now`: the halves whose credited run belongs to a heatwave not yet counted in this season
+    auto credit_k = [&](CPair &c, uint32_t lab, uint32_t fresh_now, int days) {
       const uint32_t dd = pk_dup(days) & lab;
-      const uint32_t first = lab & pk_nz(run_id ^ c.last_id);
+      const uint32_t first = lab & fresh_now;
       c.hwf = pk_add(c.hwf, dd);
       c.hwn = pk_sub(c.hwn, first);  // first is -1 per half: += 1
       c.cur = pk_add(c.cur & ~first, dd);
-      c.last_id = bsel(lab, run_id, c.last_id);
+      c.fresh = c.fresh & ~lab;
       c.hwd = pk_max(c.hwd, c.cur);
     };
     // one finished run [s, e): reference state machine + season credit, for every definition of the pass
@@ -1130,7 +1136,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
           const uint32_t ge = ~pk_lt(len, min_dur[k]);
           const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
           c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), c.subs & ~c.hw);
-          c.id = pk_sub(c.id, ge & ~sub);
+          c.fresh |= ge & ~sub;
           c.hw = sub | ge;
         }
         return;
@@ -1140,7 +1146,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
       for (int k = 0; k < NP; ++k) {
         CPair &c = st[k];
         const uint32_t ge = ~pk_lt(len, min_dur[k]);
-        if (k < NS) {  // hw, subs, id, cur, last_id of such a pair are never touched (hw stays 0)
+        if (k < NS) {  // hw, subs, fresh, cur of such a pair are never touched (hw stays 0)
           if (days > 0) {
             const uint32_t dd = pk_dup(days) & ge;
             c.hwf = pk_add(c.hwf, dd);
@@ -1152,9 +1158,9 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
         const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
         const uint32_t label = sub | ge;
         c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), c.subs & ~c.hw);
-        c.id = pk_sub(c.id, ge & ~sub);  // += 1 where a new heatwave starts
+        c.fresh |= ge & ~sub;  // a new heatwave starts
         c.hw = label;
-        if (days > 0) credit_k(c, label, c.id, days);
+        if (days > 0) credit_k(c, label, c.fresh, days);
       }
     };
     // close season si (wave-uniform) for every lane and definition
@@ -1172,7 +1178,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
         } else if (pre) {
           // a run still open dmax days past the season's end is labelled in every branch of the reference
           const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
-          credit_k(c, 0xffffffffu, pk_sub(c.id, ~sub), pre_days);  // id + 1 unless it continues as a sub-event
+          credit_k(c, 0xffffffffu, c.fresh | ~sub, pre_days);  // a heatwave of its own unless it continues as a sub-event
         }
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
@@ -1191,7 +1197,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
           }
         }
         c.hwf = c.hwn = c.hwd = c.cur = 0;
-        c.last_id = 0;
+        c.fresh = 0xffffffffu;  // the next season counts a heatwave that runs on into it again
       }
       si += 1;
       if (si < Y) {
