@@ -1029,6 +1029,7 @@ __device__ __forceinline__ uint32_t pk_nz(uint32_t x) {                         
   asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(t) : "v"(x));
   return pk_bits((pk16)(0 - pk_of(t)));
 }
+__device__ __forceinline__ uint32_t pk_neg(uint32_t a) { return pk_bits(pk_of(a) >> (short)15); }  // a < 0 ? 0xffff : 0 per half
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_bits(pk_of(a) + pk_of(b)); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_bits(pk_of(a) - pk_of(b)); }
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
@@ -1037,7 +1038,7 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t bsel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 
 struct CPair {  // two definitions' state, one per 16-bit half
-  uint32_t hw, subs;  // hw: 0xffff while a heatwave is active
+  uint32_t hw, subs;  // hw: 0xffff while a heatwave is active; subs: sub-events so far MINUS max_subs (negative: room left)
   // fresh: 0xffff while the current heatwave has not been credited in the current season yet.  The reference numbers
   // its heatwaves (id) and counts one when a credited run's id differs from the last credited one (last_id, reset with
   // the season): "differs" is exactly "a heatwave started, or the season changed, since the last credit" -- one flag
@@ -1068,7 +1069,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
   const unsigned long long *slot8 = reinterpret_cast<const unsigned long long *>(slot);
 
   // definition parameters of this pass, packed (wave-uniform); slots past D never label and are not stored
-  uint32_t min_dur[NP], max_break[NP], max_subs[NP];
+  uint32_t min_dur[NP], max_break[NP], max_subs[NP], neg_subs[NP];
   int mmin = 0x7fffffff;
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
@@ -1086,6 +1087,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
       if (real) mmin = min(mmin, max(md_, 1));
     }
     min_dur[k] = a; max_break[k] = b; max_subs[k] = c;
+    neg_subs[k] = pk_sub(0u, c);  // sub-events are counted from -max_subs up: room left is the sign bit
   }
   // A definition with max_break = 0 ends its heatwave at every gap (metric.py:48-49: a gap is >= 1 day), so it never has a
   // sub-event, every labelled run is a heatwave of its own and no state crosses a gap: a pair of two such definitions
@@ -1112,7 +1114,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
     }
     CPair st[NP];
 #pragma unroll
-    for (int k = 0; k < NP; ++k) st[k] = CPair{0, 0, 0xffffffffu, 0, 0, 0, 0};
+    for (int k = 0; k < NP; ++k) st[k] = CPair{0, neg_subs[k], 0xffffffffu, 0, 0, 0, 0};
     int open = 0, s_open = 0, e_prev = -(1 << 30);
 
     // `lab`: 0xffff in the halves whose definition labels the run; days > 0 of it fall inside the current season
@@ -1134,8 +1136,8 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
         for (int k = NS; k < NP; ++k) {
           CPair &c = st[k];
           const uint32_t ge = ~pk_lt(len, min_dur[k]);
-          const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
-          c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), c.subs & ~c.hw);
+          const uint32_t sub = c.hw & pk_neg(c.subs);  // room for another sub-event
+          c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), bsel(c.hw, neg_subs[k], c.subs));
           c.fresh |= ge & ~sub;
           c.hw = sub | ge;
         }
@@ -1155,9 +1157,9 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
           }
           continue;
         }
-        const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
+        const uint32_t sub = c.hw & pk_neg(c.subs);  // room for another sub-event
         const uint32_t label = sub | ge;
-        c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), c.subs & ~c.hw);
+        c.subs = bsel(sub, pk_add(c.subs, 0x00010001u), bsel(c.hw, neg_subs[k], c.subs));
         c.fresh |= ge & ~sub;  // a new heatwave starts
         c.hw = label;
         if (days > 0) credit_k(c, label, c.fresh, days);
@@ -1177,7 +1179,7 @@ __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(
           c.hwd = pk_max(c.hwd, dd);
         } else if (pre) {
           // a run still open dmax days past the season's end is labelled in every branch of the reference
-          const uint32_t sub = c.hw & pk_lt(c.subs, max_subs[k]);
+          const uint32_t sub = c.hw & pk_neg(c.subs);  // room for another sub-event
           credit_k(c, 0xffffffffu, c.fresh | ~sub, pre_days);  // a heatwave of its own unless it continues as a sub-event
         }
 #pragma unroll
