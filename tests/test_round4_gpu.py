@@ -210,3 +210,40 @@ def test_c5_full_grid_192x288_cells_x_10_members():
     met_g = np.transpose(og, (1, 2, 4, 5, 0, 3)).reshape(P, D, M * idx.size, 4, Y).astype(np.int64)
     hemi = np.tile((lat[idx] < 0).astype(np.uint8), M)
     assert np.array_equal(met_g, c_oracle.metrics(xs_m, np.concatenate([th_g] * M), dm, DEFS, north, south, hemi))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_rank_selection_on_long_columns_with_ties_and_special_values(seed):
+    """The ensemble shape's selection (S = 600 .. 1000 samples per day of year; value-pivot rounds, popped finish, the
+    key-pivot loop behind them) on inputs it was not tuned on: heavy ties (rounded data: the secant stalls, whole tie
+    groups straddle the wanted rank), constant cells, +-inf, a NaN, narrow and wide windows, shallow and deep ranks
+    including q = 0 and q = 1, and the duplicate columns of the windows past the year's end -- against the C oracle."""
+    from hdp_amd import calendar as cal
+    from oracle import c_oracle, hdp_oracle as orc
+    from tests.test_gpu_parity import same_f64
+    rng = np.random.default_rng(4400 + seed)
+    members = int(rng.choice([6, 8, 10]))
+    dates = orc.noleap_date_range("2001-01-01", "2100-12-31")
+    T = dates.size
+    n_cells = 3
+    x = rng.normal(10, 4, size=(members, n_cells, T)).astype(np.float32)
+    mode = seed % 4
+    if mode == 0:
+        x = np.round(x)                          # ~30 distinct values: tie groups of hundreds
+    elif mode == 1:
+        x[:, 1] = np.float32(7.5)                # a constant cell
+        x[:, 2] = np.round(x[:, 2], 1)
+    elif mode == 2:
+        x[0, 0, rng.integers(0, T, 40)] = np.inf
+        x[1, 0, rng.integers(0, T, 40)] = -np.inf
+        x[2, 1, rng.integers(0, T)] = np.nan
+    cat = np.concatenate([x[m] for m in range(members)], axis=1)
+    radius = int(rng.choice([3, 7]))
+    ti, cols = cal.window_columns(np.concatenate([dates] * members), radius)
+    q = np.sort(np.concatenate([rng.random(12), [0.0, 1.0, 0.5, 0.999]]))
+    assert "select" in core.ThresholdPlan(ti, cols, q, cat.shape[1]).describe()      # the path under test
+    with np.errstate(invalid="ignore"):
+        thr = core.compute_percentiles(cat, ti, cols, q)
+        rows = [0, 1, 180, 200, 358, 359, 362, 364]
+        want = c_oracle.thresholds(cat, cal.expand_window_table(ti, cols)[rows], q)
+    assert same_f64(thr[:, rows], want), (seed, members, radius)
