@@ -1047,8 +1047,10 @@ struct CPair {  // two definitions' state, one per 16-bit half
   uint32_t hwf, hwn, hwd, cur;
 };
 
+// waves per SIMD the register allocation aims at (min, max).  (1, 5) until the `fresh` flag freed two registers; with 65 a
+// sixth wave fits: 17.06 against 17.41 ms per 131 072 series over three A/B pairs on one box ((1, 4) 17.6, (1, 7) 17.5)
 #ifndef HDP_C16_WAVES
-#define HDP_C16_WAVES 1, 5
+#define HDP_C16_WAVES 1, 6
 #endif
 template <int NP, int NS>  // NP pairs of definitions per lane, the first NS of them "simple" (see below)
 __global__ __launch_bounds__(kMetWaves * 64) __attribute__((amdgpu_waves_per_eu(HDP_C16_WAVES))) void metrics_kernel_cells16(
